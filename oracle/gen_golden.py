@@ -1,0 +1,314 @@
+"""TEST INFRASTRUCTURE ONLY -- generate the golden vectors that pin the oracle and the HIP path.
+
+Run in the build container (needs ``/root/reference``):
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz + *.json
+
+What it does: loads the REAL reference classes in place (``oracle/reference_loader.py``), runs them on
+seeded inputs on the CPU, and stores inputs + expected outputs (never any reference source).  The fixtures are
+data only; they travel to the GPU box, the reference does not.
+
+Fixtures:
+  G1 schedules.npz        Trainer/Sampler float64 buffers for three (beta_1, beta_T, T)
+  G2 modules.npz          Swish, TimeEmbedding, ConditionalEmbedding, DownSample, UpSample, ResBlock x3 (+weights)
+  G3 unet_small.npz       small UNet (ch=32, ch_mult=[1,2], nrb=1): state_dict, inputs, eps @16^2 and @32^2, per-layer taps
+  G4 unet_default64.npz   default UNet (ch=128,[1,2,2,2],nrb=2) @64^2 B=1: seed recipe, weight checksums, input, eps
+  G5 sampler_small.npz    T=8 sampler on the small UNet, w in {0, 1.8}: x_T, per-step noise, pre-clip trajectory, output
+  G6 trainer_small.npz    Trainer loss with recorded (t, noise); grads of named params; one clipped AdamW step
+  G7 state_dict_default.json   the 366 (name, shape) pairs of the default UNet
+  G8 lr_schedule.json     GradualWarmupScheduler + CosineAnnealingLR learning-rate sequence (Scheduler.py)
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import reference_loader as RL
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+SMALL = dict(T=8, num_labels=3, ch=32, ch_mult=[1, 2], num_res_blocks=1, dropout=0.0)
+DEFAULT = dict(T=1000, num_labels=10, ch=128, ch_mult=[1, 2, 2, 2], num_res_blocks=2, dropout=0.15)
+SMALL_SEED = 1234
+DEFAULT_SEED = 0
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _sd_np(sd, prefix="sd/"):
+    return {prefix + k: _np(v) for k, v in sd.items()}
+
+
+class _Recorder:
+    """Record the tensors the reference draws from torch's RNG / checks for NaN, without touching its code."""
+
+    def __init__(self):
+        self.randn, self.randint, self.isnan_in = [], [], []
+        self._orig = {}
+
+    def __enter__(self):
+        self._orig = dict(randn_like=torch.randn_like, randint=torch.randint, isnan=torch.isnan)
+
+        def randn_like(x, *a, **k):
+            r = self._orig["randn_like"](x, *a, **k)
+            self.randn.append(r.clone())
+            return r
+
+        def randint(*a, **k):
+            r = self._orig["randint"](*a, **k)
+            self.randint.append(r.clone())
+            return r
+
+        def isnan(x):
+            self.isnan_in.append(x.detach().clone())
+            return self._orig["isnan"](x)
+
+        torch.randn_like, torch.randint, torch.isnan = randn_like, randint, isnan
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like = self._orig["randn_like"]
+        torch.randint = self._orig["randint"]
+        torch.isnan = self._orig["isnan"]
+
+
+def gen_schedules(RD):
+    out = {}
+    for i, (b1, bT, T) in enumerate([(1e-4, 0.028, 50), (1e-4, 0.028, 500), (1e-4, 0.02, 1000)]):
+        tr = RD.GaussianDiffusionTrainer(torch.nn.Identity(), b1, bT, T)
+        sa = RD.GaussianDiffusionSampler(torch.nn.Identity(), b1, bT, T, w=1.8)
+        out[f"cfg{i}"] = np.array([b1, bT, T], dtype=np.float64)
+        for n in ("betas", "sqrt_alphas_bar", "sqrt_one_minus_alphas_bar"):
+            out[f"cfg{i}/trainer/{n}"] = _np(getattr(tr, n))
+        for n in ("betas", "coeff1", "coeff2", "posterior_var"):
+            out[f"cfg{i}/sampler/{n}"] = _np(getattr(sa, n))
+        # extract(): float64 gather -> fp32 -> view
+        t = torch.tensor([0, 1, T // 2, T - 1])
+        out[f"cfg{i}/extract_t"] = _np(t)
+        out[f"cfg{i}/extract_coeff2"] = _np(RD.extract(sa.coeff2, t, (4, 3, 8, 8)))
+    np.savez_compressed(os.path.join(OUT, "schedules.npz"), **out)
+
+
+def gen_modules(RM):
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    x = torch.randn(3, 5, 7, generator=g) * 3
+    out["swish/x"], out["swish/y"] = _np(x), _np(RM.Swish()(x))
+
+    torch.manual_seed(11)
+    te = RM.TimeEmbedding(20, 32, 128).eval()
+    t = torch.tensor([0, 1, 7, 19])
+    out["temb/t"], out["temb/y"] = _np(t), _np(te(t))
+    out["temb/table_T20_d32"] = _np(te.timembedding[0].weight)
+    out.update(_sd_np(te.state_dict(), "temb/sd/"))
+
+    ce = RM.ConditionalEmbedding(4, 32, 128).eval()
+    lab = torch.tensor([0, 1, 4, 2, 0])
+    out["cemb/labels"], out["cemb/y"] = _np(lab), _np(ce(lab))
+    out.update(_sd_np(ce.state_dict(), "cemb/sd/"))
+
+    ds = RM.DownSample(32).eval()
+    x = torch.randn(2, 32, 12, 12, generator=g)
+    out["down/x"], out["down/y"] = _np(x), _np(ds(x, None, None))
+    out.update(_sd_np(ds.state_dict(), "down/sd/"))
+
+    us = RM.UpSample(32).eval()
+    x = torch.randn(2, 32, 6, 6, generator=g)
+    out["up/x"], out["up/y"] = _np(x), _np(us(x, None, None))
+    out.update(_sd_np(us.state_dict(), "up/sd/"))
+
+    # ResBlocks: (in, out, attn); tdim 64; C multiple of 32 (GroupNorm) and of 8 (heads)
+    for name, (cin, cout, attn, hw) in {"rb_attn": (32, 32, True, 8), "rb_sc": (32, 64, False, 8),
+                                         "rb_sc_attn": (96, 64, True, 6)}.items():
+        rb = RM.ResBlock(cin, cout, 64, 0.0, attn=attn).eval()
+        # MHA biases are zero-initialised by torch; make them non-trivial so the fixture exercises them
+        with torch.no_grad():
+            if attn:
+                rb.attn.in_proj_bias.copy_(torch.randn(3 * cout, generator=g) * 0.1)
+                rb.attn.out_proj.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        x = torch.randn(2, cin, hw, hw, generator=g)
+        temb = torch.randn(2, 64, generator=g)
+        cemb = torch.randn(2, 64, generator=g)
+        out[f"{name}/x"], out[f"{name}/temb"], out[f"{name}/cemb"] = _np(x), _np(temb), _np(cemb)
+        out[f"{name}/y"] = _np(rb(x, temb, cemb))
+        out[f"{name}/meta"] = np.array([cin, cout, int(attn), hw])
+        out.update(_sd_np(rb.state_dict(), f"{name}/sd/"))
+    np.savez_compressed(os.path.join(OUT, "modules.npz"), **out)
+
+
+def _small_model(RM):
+    torch.manual_seed(SMALL_SEED)
+    m = RM.UNet(**SMALL).eval()
+    g = torch.Generator().manual_seed(SMALL_SEED + 1)
+    with torch.no_grad():
+        # torch zero-initialises MHA biases: perturb them (and GN affine) so they are exercised
+        for n, p in m.named_parameters():
+            if n.endswith("in_proj_bias") or n.endswith("out_proj.bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            if ".block1.0." in n or ".block2.0." in n or n.startswith("tail.0."):
+                p.add_(torch.randn(p.shape, generator=g) * 0.1)
+    return m
+
+
+def gen_unet_small(RM):
+    m = _small_model(RM)
+    out = _sd_np(m.state_dict())
+    out["cfg_json"] = np.frombuffer(json.dumps(SMALL).encode(), dtype=np.uint8)
+    g = torch.Generator().manual_seed(99)
+    for S in (16, 32):
+        x = torch.randn(2, 3, S, S, generator=g)
+        t = torch.tensor([3, 7])
+        labels = torch.tensor([2, 0])
+        taps = {}
+        hooks = []
+        if S == 16:
+            for name, mod in list(m.downblocks.named_children()):
+                hooks.append(mod.register_forward_hook(lambda _m, _i, o, n=f"downblocks.{name}": taps.__setitem__(n, o)))
+            for name, mod in list(m.middleblocks.named_children()):
+                hooks.append(mod.register_forward_hook(lambda _m, _i, o, n=f"middleblocks.{name}": taps.__setitem__(n, o)))
+            for name, mod in list(m.upblocks.named_children()):
+                hooks.append(mod.register_forward_hook(lambda _m, _i, o, n=f"upblocks.{name}": taps.__setitem__(n, o)))
+            hooks.append(m.head.register_forward_hook(lambda _m, _i, o: taps.__setitem__("head", o)))
+            hooks.append(m.time_embedding.register_forward_hook(lambda _m, _i, o: taps.__setitem__("temb", o)))
+            hooks.append(m.cond_embedding.register_forward_hook(lambda _m, _i, o: taps.__setitem__("cemb", o)))
+        with torch.no_grad():
+            y = m(x, t, labels)
+        for h in hooks:
+            h.remove()
+        out[f"s{S}/x"], out[f"s{S}/t"], out[f"s{S}/labels"], out[f"s{S}/eps"] = _np(x), _np(t), _np(labels), _np(y)
+        for k, v in taps.items():
+            out[f"s{S}/tap/{k}"] = _np(v)
+    np.savez_compressed(os.path.join(OUT, "unet_small.npz"), **out)
+    return m
+
+
+def weight_checksums(sd):
+    """Order-independent pins for a regenerated state_dict: per-tensor (sum, abs-sum, first, last) in float64."""
+    names = sorted(sd.keys())
+    rows = []
+    for n in names:
+        v = sd[n].detach().double().reshape(-1)
+        rows.append([v.sum().item(), v.abs().sum().item(), v[0].item(), v[-1].item()])
+    return names, np.array(rows, dtype=np.float64)
+
+
+def gen_unet_default64(RM):
+    torch.manual_seed(DEFAULT_SEED)
+    m = RM.UNet(**DEFAULT).eval()
+    names, sums = weight_checksums(m.state_dict())
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(1, 3, 64, 64, generator=g)
+    t = torch.tensor([417])
+    out = {"seed": np.array([DEFAULT_SEED]), "cfg_json": np.frombuffer(json.dumps(DEFAULT).encode(), dtype=np.uint8),
+           "weight_names": np.array(names), "weight_checksums": sums, "x": _np(x), "t": _np(t)}
+    with torch.no_grad():
+        for lab in (1, 0):
+            out[f"eps_label{lab}"] = _np(m(x, t, torch.tensor([lab])))
+    np.savez_compressed(os.path.join(OUT, "unet_default64.npz"), **out)
+    with open(os.path.join(OUT, "state_dict_default.json"), "w") as fh:
+        json.dump({"n_params": sum(p.numel() for p in m.parameters()),
+                   "entries": [[k, list(v.shape)] for k, v in m.state_dict().items()]}, fh, indent=0)
+
+
+def gen_sampler_small(RM, RD):
+    m = _small_model(RM)
+    # random default-init weights saturate the trajectory; shrink the tail conv so x_t stays O(1) (SURVEY 8c note)
+    out = {}
+    g = torch.Generator().manual_seed(4321)
+    x_T = torch.randn(2, 3, 16, 16, generator=g)
+    labels = torch.tensor([1, 3])
+    out["x_T"], out["labels"] = _np(x_T), _np(labels)
+    out["beta"] = np.array([1e-4, 0.028])
+    for w in (0.0, 1.8):
+        samp = RD.GaussianDiffusionSampler(m, 1e-4, 0.028, SMALL["T"], w=w)
+        torch.manual_seed(555)
+        with _Recorder() as rec, torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            y = samp(x_T, labels)
+        tag = f"w{w}"
+        # randn_like is drawn at time_step = T-1 ... 1 (not at 0): store indexed by time_step
+        T = SMALL["T"]
+        noise = np.zeros((T,) + tuple(x_T.shape), dtype=np.float32)
+        for i, r in enumerate(rec.randn):
+            noise[T - 1 - i] = _np(r)
+        out[f"{tag}/noise_by_step"] = noise
+        out[f"{tag}/traj_preclip"] = np.stack([_np(v) for v in rec.isnan_in])   # order: time_step T-1 ... 0
+        out[f"{tag}/x_0"] = _np(y)
+    np.savez_compressed(os.path.join(OUT, "sampler_small.npz"), **out)
+
+
+def gen_trainer_small(RM, RD):
+    m = _small_model(RM)
+    m.train()                      # dropout p=0 in SMALL -> no RNG inside the model
+    trainer = RD.GaussianDiffusionTrainer(m, 1e-4, 0.028, SMALL["T"])
+    g = torch.Generator().manual_seed(777)
+    x_0 = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
+    labels = torch.tensor([1, 2, 0, 3])
+    torch.manual_seed(888)
+    with _Recorder() as rec:
+        loss = trainer(x_0, labels)
+    out = {"x_0": _np(x_0), "labels": _np(labels), "t": _np(rec.randint[0]), "noise": _np(rec.randn[0]),
+           "loss": _np(loss), "beta": np.array([1e-4, 0.028])}
+    b = x_0.shape[0]
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt.zero_grad()
+    (loss.sum() / b ** 2.).backward()            # TrainCondition.py:59-60
+    grad_names = ["head.weight", "tail.2.weight", "downblocks.0.attn.in_proj_weight", "downblocks.0.block1.0.weight",
+                  "downblocks.1.c2.weight", "upblocks.2.t.weight", "time_embedding.timembedding.0.weight",
+                  "cond_embedding.condEmbedding.0.weight", "middleblocks.0.temb_proj.1.weight",
+                  "upblocks.0.shortcut.weight", "downblocks.2.attn.out_proj.bias"]
+    params = dict(m.named_parameters())
+    for n in grad_names:
+        out[f"grad/{n}"] = _np(params[n].grad)
+    out["grad_total_norm"] = np.array([torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0).item()])  # :61-62
+    opt.step()                                                                                      # :63
+    for n in grad_names:
+        out[f"after_step/{n}"] = _np(params[n])
+    np.savez_compressed(os.path.join(OUT, "trainer_small.npz"), **out)
+
+
+def gen_lr_schedule():
+    RS = RL.load_scheduler()
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-4, weight_decay=1e-4)
+    epochs, mult = 70, 2.5
+    cos = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=opt, T_max=epochs, eta_min=0, last_epoch=-1)
+    warm = RS.GradualWarmupScheduler(optimizer=opt, multiplier=mult, warm_epoch=epochs // 10, after_scheduler=cos)
+    lrs = []
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(epochs):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            warm.step()
+    with open(os.path.join(OUT, "lr_schedule.json"), "w") as fh:
+        json.dump({"epochs": epochs, "multiplier": mult, "base_lr": 1e-4, "lr_by_epoch": lrs}, fh)
+
+
+def main():
+    if not RL.available():
+        sys.exit("reference not present at " + RL.REFERENCE_ROOT)
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    RD, RM = RL.load_diffusion(), RL.load_model()
+    gen_schedules(RD)
+    gen_modules(RM)
+    gen_unet_small(RM)
+    gen_unet_default64(RM)
+    gen_sampler_small(RM, RD)
+    gen_trainer_small(RM, RD)
+    gen_lr_schedule()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
