@@ -1,0 +1,244 @@
+"""Drop-in for the reference's ``DiffusionFreeGuidence/ModelCondition.py`` (lines 1-277): same class names, constructor
+and ``forward`` signatures, parameter names/shapes (the 366-entry ``state_dict``) and default initialisation.
+
+The ``torch.nn`` leaf modules below (``nn.Conv2d``, ``nn.GroupNorm``, ``nn.Linear``, ``nn.Embedding``,
+``nn.MultiheadAttention`` ...) are used ONLY as parameter containers, created in the reference's order so that the same
+``torch.manual_seed`` gives bit-identical initial weights and the same ``state_dict`` keys.  Their own ``forward`` methods
+are never called: every ``forward`` in this file issues hand-written gfx950 kernels through ``libhdiff.so``
+(``..engine``).  On a tensor that is not on an MI355X device the forwards raise -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from .. import engine as E
+
+__all__ = ["Swish", "TimeEmbedding", "ConditionalEmbedding", "DownSample", "UpSample", "ResBlock", "UNet"]
+
+
+def _params_of(mod: nn.Module, prefix: str = "") -> Dict[str, torch.Tensor]:
+    return {prefix + k: v for k, v in mod.state_dict(keep_vars=True).items()}
+
+
+def _check_inputs(**tensors: torch.Tensor) -> None:
+    for name, t in tensors.items():
+        E.require_gpu_tensor(t, name)
+
+
+class _EagerMixin:
+    """Run a sub-module on its own: build a one-off plan, pack its weights, launch, return a fresh tensor."""
+
+    @staticmethod
+    def _finish(plan: E.Plan, out: torch.Tensor) -> torch.Tensor:
+        plan.pack_weights()
+        plan.run()
+        return out.clone()
+
+
+class Swish(nn.Module):
+    """x * sigmoid(x) (reference ModelCondition.py:22-24).  Inside the UNet it is fused into the consuming kernels."""
+
+    def forward(self, x):
+        _check_inputs(x=x)
+        plan = E.Plan(x.device)
+        n = x.numel()
+        one = torch.ones(1, device=x.device)
+        zero = torch.zeros(1, device=x.device)
+        y = torch.empty_like(x)
+        plan.call("hdiff_gn_swish_apply", x.data_ptr(), one.data_ptr(), zero.data_ptr(), y.data_ptr(), 1, 1, n)
+        plan.run()
+        return y
+
+
+class TimeEmbedding(nn.Module, _EagerMixin):
+    """Sinusoidal table (trainable) -> Linear -> Swish -> Linear (reference ModelCondition.py:27-49)."""
+
+    def __init__(self, T, d_model, dim):
+        assert d_model % 2 == 0
+        super().__init__()
+        freqs = torch.exp(-(torch.arange(0, d_model, step=2) / d_model * math.log(10000)))
+        ang = torch.arange(T).float()[:, None] * freqs[None, :]
+        table = torch.stack([torch.sin(ang), torch.cos(ang)], dim=-1).view(T, d_model)
+        self.timembedding = nn.Sequential(
+            nn.Embedding.from_pretrained(table, freeze=False),
+            nn.Linear(d_model, dim),
+            Swish(),
+            nn.Linear(dim, dim),
+        )
+
+    def forward(self, t):
+        _check_inputs(t=t)
+        plan = E.Plan(t.device)
+        out = E.emit_embed_mlp(plan, _params_of(self.timembedding, "e."), "e", t, int(t.shape[0]))
+        return self._finish(plan, out)
+
+
+class ConditionalEmbedding(nn.Module, _EagerMixin):
+    """Embedding(num_labels+1, padding_idx=0) -> Linear -> Swish -> Linear (reference ModelCondition.py:52-65)."""
+
+    def __init__(self, num_labels, d_model, dim):
+        assert d_model % 2 == 0
+        super().__init__()
+        self.condEmbedding = nn.Sequential(
+            nn.Embedding(num_embeddings=num_labels + 1, embedding_dim=d_model, padding_idx=0),
+            nn.Linear(d_model, dim),
+            Swish(),
+            nn.Linear(dim, dim),
+        )
+
+    def forward(self, t):
+        _check_inputs(labels=t)
+        plan = E.Plan(t.device)
+        out = E.emit_embed_mlp(plan, _params_of(self.condEmbedding, "e."), "e", t, int(t.shape[0]))
+        return self._finish(plan, out)
+
+
+class DownSample(nn.Module, _EagerMixin):
+    """Conv3x3/s2 + Conv5x5/s2, summed (reference ModelCondition.py:68-76); temb/cemb are ignored."""
+
+    def __init__(self, in_ch):
+        super().__init__()
+        self.c1 = nn.Conv2d(in_ch, in_ch, 3, stride=2, padding=1)
+        self.c2 = nn.Conv2d(in_ch, in_ch, 5, stride=2, padding=2)
+
+    def forward(self, x, temb, cemb):
+        _check_inputs(x=x)
+        B, Cc, H, W = (int(v) for v in x.shape)
+        plan = E.Plan(x.device)
+        return self._finish(plan, E.emit_downsample(plan, _params_of(self, "m."), "m", x, B, Cc, H, W))
+
+
+class UpSample(nn.Module, _EagerMixin):
+    """ConvTranspose2d(5, 2, 2, 1) then Conv3x3 (reference ModelCondition.py:79-89)."""
+
+    def __init__(self, in_ch):
+        super().__init__()
+        self.c = nn.Conv2d(in_ch, in_ch, 3, stride=1, padding=1)
+        self.t = nn.ConvTranspose2d(in_ch, in_ch, 5, 2, 2, 1)
+
+    def forward(self, x, temb, cemb):
+        _check_inputs(x=x)
+        B, Cc, H, W = (int(v) for v in x.shape)
+        plan = E.Plan(x.device)
+        return self._finish(plan, E.emit_upsample(plan, _params_of(self, "m."), "m", x, B, Cc, H, W))
+
+
+class ResBlock(nn.Module, _EagerMixin):
+    """GN-Swish-Conv (+temb +cemb) -> GN-Swish-Dropout-Conv -> + shortcut(x) -> optional 8-head self-attention
+    with no pre-norm and no residual (reference ModelCondition.py:166-211)."""
+
+    def __init__(self, in_ch, out_ch, tdim, dropout, attn=True):
+        super().__init__()
+        self.block1 = nn.Sequential(nn.GroupNorm(32, in_ch), Swish(), nn.Conv2d(in_ch, out_ch, 3, stride=1, padding=1))
+        self.temb_proj = nn.Sequential(Swish(), nn.Linear(tdim, out_ch))
+        self.cond_proj = nn.Sequential(Swish(), nn.Linear(tdim, out_ch))
+        self.block2 = nn.Sequential(nn.GroupNorm(32, out_ch), Swish(), nn.Dropout(dropout),
+                                    nn.Conv2d(out_ch, out_ch, 3, stride=1, padding=1))
+        self.attn = nn.MultiheadAttention(out_ch, num_heads=8) if attn else nn.Identity()
+        self.shortcut = nn.Conv2d(in_ch, out_ch, 1, stride=1, padding=0) if in_ch != out_ch else nn.Identity()
+        self.out_ch = out_ch
+
+    def forward(self, x, temb, cemb=None):
+        _check_inputs(x=x, temb=temb)
+        _refuse_dropout(self)
+        B, _, H, W = (int(v) for v in x.shape)
+        plan = E.Plan(x.device)
+        has_attn = isinstance(self.attn, nn.MultiheadAttention)
+        out = E.emit_resblock(plan, _params_of(self, "m."), "m", x, None, temb, cemb, self.out_ch, B, H, W, has_attn)
+        return self._finish(plan, out)
+
+
+def _refuse_dropout(mod: nn.Module) -> None:
+    for m in mod.modules():
+        if isinstance(m, nn.Dropout) and m.training and m.p > 0:
+            raise NotImplementedError("hdiff: train-mode dropout (p > 0) is not built yet on the HIP path; call .eval() "
+                                      "or construct the model with dropout=0")
+
+
+class UNet(nn.Module):
+    """Conditional U-Net denoiser (reference ModelCondition.py:213-276): forward(x[B,3,H,W], t[B], labels[B]) -> eps."""
+
+    def __init__(self, T, num_labels, ch, ch_mult, num_res_blocks, dropout):
+        super().__init__()
+        tdim = ch * 4
+        self.time_embedding = TimeEmbedding(T, ch, tdim)
+        self.cond_embedding = ConditionalEmbedding(num_labels, ch, tdim)
+        self.head = nn.Conv2d(3, ch, kernel_size=3, stride=1, padding=1)
+        self.downblocks = nn.ModuleList()
+        widths = [ch]
+        now = ch
+        last_level = len(ch_mult) - 1
+        for level, mult in enumerate(ch_mult):
+            for _ in range(num_res_blocks):
+                self.downblocks.append(ResBlock(in_ch=now, out_ch=ch * mult, tdim=tdim, dropout=dropout))
+                now = ch * mult
+                widths.append(now)
+            if level != last_level:
+                self.downblocks.append(DownSample(now))
+                widths.append(now)
+        self.middleblocks = nn.ModuleList([ResBlock(now, now, tdim, dropout, attn=True),
+                                           ResBlock(now, now, tdim, dropout, attn=False)])
+        self.upblocks = nn.ModuleList()
+        for level in range(last_level, -1, -1):
+            for _ in range(num_res_blocks + 1):
+                self.upblocks.append(ResBlock(in_ch=widths.pop() + now, out_ch=ch * ch_mult[level], tdim=tdim,
+                                              dropout=dropout, attn=False))
+                now = ch * ch_mult[level]
+            if level != 0:
+                self.upblocks.append(UpSample(now))
+        assert len(widths) == 0
+        self.tail = nn.Sequential(nn.GroupNorm(32, now), Swish(), nn.Conv2d(now, 3, 3, stride=1, padding=1))
+        self._shape = E.UNetShape(T=T, num_labels=num_labels, ch=ch, ch_mult=tuple(ch_mult), num_res_blocks=num_res_blocks)
+        self._plans: Dict[tuple, E.UNetPlan] = {}
+        self._plan_ptrs: Optional[tuple] = None
+        self._packed_versions: Dict[tuple, tuple] = {}
+
+    # -- plan cache ---------------------------------------------------------------------------------------------------
+    def _param_signature(self):
+        ps = list(self.parameters())
+        return tuple(p.data_ptr() for p in ps), tuple(p._version for p in ps)
+
+    def plan_for(self, B: int, H: int, W: int, device) -> E.UNetPlan:
+        """Launch plan for (B, H, W) with up-to-date packed weights (repacked whenever a parameter changed)."""
+        ptrs, versions = self._param_signature()
+        if ptrs != self._plan_ptrs:
+            self._plans.clear()
+            self._packed_versions.clear()
+            self._plan_ptrs = ptrs
+        key = (B, H, W, str(device))
+        up = self._plans.get(key)
+        if up is None:
+            up = E.UNetPlan(_params_of(self), self._shape, B, H, W, device)
+            self._plans[key] = up
+        if self._packed_versions.get(key) != versions:
+            up.plan.pack_weights()
+            self._packed_versions[key] = versions
+        return up
+
+    def check_indices(self, t, labels) -> None:
+        """nn.Embedding raises IndexError on an out-of-range index (reference ModelCondition.py:38,56); the kernels clamp
+        instead of faulting, so the range is validated here (one device->host read)."""
+        lim = torch.stack([t.min(), t.max(), labels.min(), labels.max()]).tolist()
+        if lim[0] < 0 or lim[1] >= self._shape.T or lim[2] < 0 or lim[3] > self._shape.num_labels:
+            raise IndexError("index out of range in self")
+
+    def forward(self, x, t, labels):
+        _check_inputs(x=x, t=t, labels=labels)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ..autograd import unet_forward_with_grad
+            return unet_forward_with_grad(self, x, t, labels)
+        _refuse_dropout(self)
+        B, Cx, H, W = (int(v) for v in x.shape)
+        if Cx != 3:
+            raise RuntimeError(f"expected input[{B}, {Cx}, {H}, {W}] to have 3 channels")
+        self.check_indices(t, labels)
+        up = self.plan_for(B, H, W, x.device)
+        up.x.copy_(x)
+        up.t.copy_(t)
+        up.labels.copy_(labels)
+        up.plan.run()
+        return up.out.clone()

@@ -1,0 +1,3 @@
+"""Same module paths as the reference package ``DiffusionFreeGuidence`` (its __init__.py star-imports the three modules)."""
+from .DiffusionCondition import *   # noqa: F401,F403
+from .ModelCondition import *       # noqa: F401,F403

@@ -1,0 +1,44 @@
+// Shared helpers for the gfx950 kernels of the CFG-DDPM hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/hdiff.h"
+
+namespace hdiff {
+
+void set_error(const char* fmt, ...);
+
+#define HDIFF_CHECK_ARG(cond, ...)            \
+  do {                                        \
+    if (!(cond)) {                            \
+      hdiff::set_error(__VA_ARGS__);          \
+      return HDIFF_ERR_INVALID;               \
+    }                                         \
+  } while (0)
+
+#define HDIFF_CHECK_LAUNCH(what)                                                   \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      hdiff::set_error("%s: %s", what, hipGetErrorString(e__));                    \
+      return HDIFF_ERR_LAUNCH;                                                     \
+    }                                                                              \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float swishf(float v) { return v / (1.0f + __expf(-v)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace hdiff

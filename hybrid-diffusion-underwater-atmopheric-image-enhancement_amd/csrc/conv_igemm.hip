@@ -1,0 +1,303 @@
+// Implicit-GEMM convolution on the fp32-input MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// One kernel serves every convolution of the hot path (reference call sites: ModelCondition.py:71-75, 82-88, 172, 186,
+// 192, 219, 251 and the 1x1-conv view of nn.MultiheadAttention's projections, :189):
+//     D[co][pixel] = sum_{tap, ci} Wp[tap][ci][co] * act(X[ci][pixel*stride + tap])
+// GEMM roles: A = weights (M = 64 output channels per block), B = activations (N = 128 or 256 output pixels per block),
+// K = taps x input channels, walked in chunks of CK channels.  Per chunk the block stages
+//   * the NCHW input patch (tile + halo) of CK channels into LDS once -- every tap reads it at a shifted address, and
+//     GroupNorm-affine + Swish (the reference's block1/block2 prologue) is applied while staging,
+//   * the packed weight slab [ntaps][CK][64] with 16-byte loads.
+// Each wave owns 64 channels x (32*WN) pixels: 2 x WN accumulators of 32x32 (16 VGPRs each).
+// fp32 MFMA is exact fp32 (a k-ordered fma chain), so results differ from the reference only by summation order.
+#include "common.h"
+
+using namespace hdiff;
+
+namespace {
+
+constexpr int BM = 64;
+constexpr int NTHREADS = 256;
+
+struct ConvK {
+  const float* x0;
+  const float* x1;
+  int C0, C1, Cin, H, W;
+  const float* wp;
+  int CinPad, CoutPad, Cout;
+  const float* bias;
+  const float* gn_scale;
+  const float* gn_shift;
+  const float* addvec;
+  const float* residual;
+  float* out;
+  int OH, OW, VH, VW, in_stride, out_sy, out_oy, out_sx, out_ox;
+  int ntaps, dy_min, dx_min, PH, PW, PWp, PLANE, XFLOATS;
+  int tw_log2, TH, tiles_x;
+  int tap_off[HDIFF_MAX_TAPS];
+};
+
+template <int WN, int CK>
+__global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sX = smem;               // [CK][PLANE]
+  float* sW = smem + p.XFLOATS;   // [ntaps][CK][BM]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z;
+  const int co0 = blockIdx.y * BM;
+  const int tile_y = blockIdx.x / p.tiles_x, tile_x = blockIdx.x - tile_y * p.tiles_x;
+  const int TWm1 = (1 << p.tw_log2) - 1;
+  const int vy0 = tile_y * p.TH, vx0 = tile_x << p.tw_log2;
+  const int iy0 = vy0 * p.in_stride + p.dy_min, ix0 = vx0 * p.in_stride + p.dx_min;
+  const bool has_gn = p.gn_scale != nullptr;
+
+  int pixoff[WN];
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int pidx = (wave * WN + nt) * 32 + l31;
+    pixoff[nt] = ((pidx >> p.tw_log2) * p.PWp + (pidx & TWm1)) * p.in_stride;
+  }
+
+  f32x16 acc[2][WN];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const bool two_m = (p.Cout - co0) > 32;
+  const size_t HW = (size_t)p.H * p.W;
+
+  for (int c0 = 0; c0 < p.CinPad; c0 += CK) {
+    __syncthreads();
+    // ---- stage the activation patch: one half-wave per (channel, patch row)
+    {
+      const int l32 = tid & 31;
+      int ci = 0, py = tid >> 5;
+      while (py >= p.PH) { py -= p.PH; ++ci; }
+      while (ci < CK) {
+        const int c = c0 + ci;
+        const int iy = iy0 + py;
+        const bool row_ok = (c < p.Cin) && (iy >= 0) && (iy < p.H);
+        const float* src = nullptr;
+        float sc = 1.f, sh = 0.f;
+        if (row_ok) {
+          src = (c < p.C0) ? p.x0 + ((size_t)b * p.C0 + c) * HW : p.x1 + ((size_t)b * p.C1 + (c - p.C0)) * HW;
+          src += (size_t)iy * p.W;
+          if (has_gn) {
+            sc = p.gn_scale[b * p.Cin + c];
+            sh = p.gn_shift[b * p.Cin + c];
+          }
+        }
+        float* dst = sX + ci * p.PLANE + py * p.PWp;
+        for (int px = l32; px < p.PW; px += 32) {
+          const int ix = ix0 + px;
+          float v = 0.f;
+          if (row_ok && ix >= 0 && ix < p.W) {
+            v = src[ix];
+            if (has_gn) v = swishf(fmaf(v, sc, sh));
+          }
+          dst[px] = v;
+        }
+        py += 8;
+        while (py >= p.PH) { py -= p.PH; ++ci; }
+      }
+    }
+    // ---- stage the weight slab [ntaps][CK][BM] (rows of 64 floats, 16-byte accesses)
+    {
+      const int nvec = p.ntaps * CK * (BM / 4);
+      for (int idx = tid; idx < nvec; idx += NTHREADS) {
+        const int row = idx >> 4, seg = idx & 15;
+        const int tap = row / CK, ci = row - tap * CK;
+        const float4* g =
+            reinterpret_cast<const float4*>(p.wp + ((size_t)tap * p.CinPad + c0 + ci) * p.CoutPad + co0) + seg;
+        reinterpret_cast<float4*>(sW)[idx] = *g;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over taps x k-pairs.  Lane half h supplies k = 2*k2 + h for both operands.
+    for (int tap = 0; tap < p.ntaps; ++tap) {
+      const float* xb = sX + p.tap_off[tap] + h * p.PLANE;
+      const float* wb = sW + (tap * CK + h) * BM + l31;
+#pragma unroll
+      for (int k2 = 0; k2 < CK / 2; ++k2) {
+        const float a0 = wb[(2 * k2) * BM];
+        const float a1 = wb[(2 * k2) * BM + 32];
+        float bf[WN];
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) bf[nt] = xb[(2 * k2) * p.PLANE + pixoff[nt]];
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[nt], acc[0][nt], 0, 0, 0);
+        if (two_m) {
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt)
+            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[nt], acc[1][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: + bias + per-sample channel vector + residual, NCHW store (32 consecutive pixels per register row)
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int pidx = (wave * WN + nt) * 32 + l31;
+    const int vy = vy0 + (pidx >> p.tw_log2), vx = vx0 + (pidx & TWm1);
+    if (vy >= p.VH || vx >= p.VW) continue;
+    const int oy = vy * p.out_sy + p.out_oy, ox = vx * p.out_sx + p.out_ox;
+    const size_t pix = (size_t)oy * p.OW + ox;
+    const size_t plane = (size_t)p.OH * p.OW;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (mt == 1 && !two_m) break;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < p.Cout) {
+          float v = acc[mt][nt][r];
+          if (p.bias) v += p.bias[co];
+          if (p.addvec) v += p.addvec[b * p.Cout + co];
+          const size_t o = ((size_t)b * p.Cout + co) * plane + pix;
+          if (p.residual) v += p.residual[o];
+          p.out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+struct PackK {
+  int mode, Cout, Cin, KH, KW, ntaps, CinPad, CoutPad, accumulate;
+  int ky[HDIFF_MAX_TAPS];
+  int kx[HDIFF_MAX_TAPS];
+};
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, const PackK p) {
+  const size_t n = (size_t)p.ntaps * p.CinPad * p.CoutPad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % p.CoutPad);
+    const size_t r = i / p.CoutPad;
+    const int ci = (int)(r % p.CinPad);
+    const int tap = (int)(r / p.CinPad);
+    float v = 0.f;
+    const int ky = p.ky[tap], kx = p.kx[tap];
+    if (co < p.Cout && ci < p.Cin && ky >= 0) {
+      const size_t src = (p.mode == 0) ? (((size_t)co * p.Cin + ci) * p.KH + ky) * p.KW + kx
+                                       : (((size_t)ci * p.Cout + co) * p.KH + ky) * p.KW + kx;
+      v = w[src];
+    }
+    wp[i] = p.accumulate ? wp[i] + v : v;
+  }
+}
+
+int ceil_log2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+template <int WN, int CK>
+int launch(const ConvK& k, int B, size_t lds_bytes, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WN, CK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int BN = 128 * WN;
+  const int TW = 1 << k.tw_log2;
+  const int tiles_y = cdiv(k.VH, BN / TW);
+  dim3 grid(k.tiles_x * tiles_y, cdiv(k.Cout, BM), B);
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL((conv_igemm_kernel<WN, CK>), grid, dim3(NTHREADS), lds_bytes, stream, k);
+  HDIFF_CHECK_LAUNCH("conv_igemm_kernel");
+  return HDIFF_OK;
+}
+
+}  // namespace
+
+extern "C" int hdiff_pack_conv_weight(const float* w, float* wp, int mode, int Cout, int Cin, int KH, int KW, int ntaps,
+                                      const int* tap_ky, const int* tap_kx, int CinPad, int CoutPad, int accumulate,
+                                      hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(w && wp && tap_ky && tap_kx, "pack_conv_weight: null pointer");
+  HDIFF_CHECK_ARG(ntaps >= 1 && ntaps <= HDIFF_MAX_TAPS, "pack_conv_weight: ntaps %d out of range", ntaps);
+  HDIFF_CHECK_ARG(CinPad >= Cin && CinPad % 8 == 0 && CoutPad >= Cout && CoutPad % 64 == 0,
+                  "pack_conv_weight: CinPad %% 8 / CoutPad %% 64 violated (%d, %d)", CinPad, CoutPad);
+  PackK p{};
+  p.mode = mode; p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.ntaps = ntaps;
+  p.CinPad = CinPad; p.CoutPad = CoutPad; p.accumulate = accumulate;
+  for (int t = 0; t < ntaps; ++t) {
+    HDIFF_CHECK_ARG(tap_ky[t] < KH && tap_kx[t] < KW, "pack_conv_weight: tap %d outside the kernel", t);
+    p.ky[t] = tap_ky[t];
+    p.kx[t] = tap_kx[t];
+  }
+  const size_t n = (size_t)ntaps * CinPad * CoutPad;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, p);
+  HDIFF_CHECK_LAUNCH("pack_conv_weight_kernel");
+  return HDIFF_OK;
+}
+
+extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(d && d->x0 && d->wp && d->out, "conv2d_fwd: null pointer");
+  HDIFF_CHECK_ARG(d->C1 == 0 || d->x1, "conv2d_fwd: C1 > 0 without x1");
+  HDIFF_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= HDIFF_MAX_TAPS, "conv2d_fwd: ntaps %d out of range", d->ntaps);
+  HDIFF_CHECK_ARG(d->CinPad >= d->C0 + d->C1 && d->CinPad % 8 == 0 && d->CoutPad >= d->Cout && d->CoutPad % 64 == 0,
+                  "conv2d_fwd: padded channel counts invalid (Cin %d CinPad %d Cout %d CoutPad %d)", d->C0 + d->C1,
+                  d->CinPad, d->Cout, d->CoutPad);
+  HDIFF_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->VH > 0 && d->VW > 0 && d->in_stride >= 1 && d->in_stride <= 2,
+                  "conv2d_fwd: bad geometry");
+  HDIFF_CHECK_ARG((d->VH - 1) * d->out_sy + d->out_oy < d->OH && (d->VW - 1) * d->out_sx + d->out_ox < d->OW,
+                  "conv2d_fwd: virtual grid maps outside the output tensor");
+  HDIFF_CHECK_ARG((d->gn_scale == nullptr) == (d->gn_shift == nullptr), "conv2d_fwd: gn_scale/gn_shift must come together");
+
+  ConvK k{};
+  k.x0 = d->x0; k.x1 = d->x1; k.C0 = d->C0; k.C1 = d->C1; k.Cin = d->C0 + d->C1; k.H = d->H; k.W = d->W;
+  k.wp = d->wp; k.CinPad = d->CinPad; k.CoutPad = d->CoutPad; k.Cout = d->Cout;
+  k.bias = d->bias; k.gn_scale = d->gn_scale; k.gn_shift = d->gn_shift; k.addvec = d->addvec; k.residual = d->residual;
+  k.out = d->out; k.OH = d->OH; k.OW = d->OW; k.VH = d->VH; k.VW = d->VW; k.in_stride = d->in_stride;
+  k.out_sy = d->out_sy; k.out_oy = d->out_oy; k.out_sx = d->out_sx; k.out_ox = d->out_ox; k.ntaps = d->ntaps;
+
+  int dy_min = d->tap_dy[0], dy_max = d->tap_dy[0], dx_min = d->tap_dx[0], dx_max = d->tap_dx[0];
+  for (int t = 1; t < d->ntaps; ++t) {
+    dy_min = d->tap_dy[t] < dy_min ? d->tap_dy[t] : dy_min;
+    dy_max = d->tap_dy[t] > dy_max ? d->tap_dy[t] : dy_max;
+    dx_min = d->tap_dx[t] < dx_min ? d->tap_dx[t] : dx_min;
+    dx_max = d->tap_dx[t] > dx_max ? d->tap_dx[t] : dx_max;
+  }
+  k.dy_min = dy_min; k.dx_min = dx_min;
+
+  const int WN = ((long)d->VH * d->VW >= 1024) ? 2 : 1;
+  const int BN = 128 * WN;
+  int twl = ceil_log2(d->VW);
+  if (twl > 5) twl = 5;
+  k.tw_log2 = twl;
+  const int TW = 1 << twl;
+  k.TH = BN / TW;
+  k.tiles_x = cdiv(d->VW, TW);
+  k.PH = (k.TH - 1) * d->in_stride + (dy_max - dy_min + 1);
+  k.PW = (TW - 1) * d->in_stride + (dx_max - dx_min + 1);
+  k.PWp = k.PW | 1;
+  k.PLANE = k.PH * k.PWp;
+  for (int t = 0; t < d->ntaps; ++t) k.tap_off[t] = (d->tap_dy[t] - dy_min) * k.PWp + (d->tap_dx[t] - dx_min);
+
+  int CK = 8;
+  auto lds_for = [&](int ck) {
+    const int xfl = (ck * k.PLANE + 3) & ~3;
+    return (size_t)(xfl + d->ntaps * ck * BM) * sizeof(float);
+  };
+  if (lds_for(8) > 48 * 1024) CK = 4;
+  const size_t lds = lds_for(CK);
+  HDIFF_CHECK_ARG(lds <= 160 * 1024, "conv2d_fwd: tile needs %zu bytes of LDS", lds);
+  k.XFLOATS = (CK * k.PLANE + 3) & ~3;
+
+  hipStream_t s = (hipStream_t)stream;
+  if (WN == 2 && CK == 8) return launch<2, 8>(k, d->B, lds, s);
+  if (WN == 2 && CK == 4) return launch<2, 4>(k, d->B, lds, s);
+  if (WN == 1 && CK == 8) return launch<1, 8>(k, d->B, lds, s);
+  return launch<1, 4>(k, d->B, lds, s);
+}

@@ -1,0 +1,100 @@
+// Error reporting, device query, hipGraph and event helpers of the C ABI (include/hdiff.h).
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace hdiff {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace hdiff
+
+extern "C" {
+
+int hdiff_abi_version(void) { return 1; }
+const char* hdiff_last_error(void) { return hdiff::g_err; }
+
+int hdiff_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int hdiff_graph_begin(hdiff_stream_t stream) {
+  hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    hdiff::set_error("hipStreamBeginCapture: %s", hipGetErrorString(e));
+    return HDIFF_ERR_LAUNCH;
+  }
+  return HDIFF_OK;
+}
+
+int hdiff_graph_end(hdiff_stream_t stream, void** graph_exec_out) {
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
+  if (e != hipSuccess || graph == nullptr) {
+    hdiff::set_error("hipStreamEndCapture: %s", hipGetErrorString(e));
+    return HDIFF_ERR_LAUNCH;
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    hdiff::set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+    return HDIFF_ERR_LAUNCH;
+  }
+  *graph_exec_out = (void*)exec;
+  return HDIFF_OK;
+}
+
+int hdiff_graph_launch(void* graph_exec, hdiff_stream_t stream) {
+  hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    hdiff::set_error("hipGraphLaunch: %s", hipGetErrorString(e));
+    return HDIFF_ERR_LAUNCH;
+  }
+  return HDIFF_OK;
+}
+
+int hdiff_graph_destroy(void* graph_exec) {
+  if (graph_exec) hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  return HDIFF_OK;
+}
+
+int hdiff_event_create(void** ev) {
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) {
+    hdiff::set_error("hipEventCreate failed");
+    return HDIFF_ERR_LAUNCH;
+  }
+  *ev = (void*)e;
+  return HDIFF_OK;
+}
+int hdiff_event_record(void* ev, hdiff_stream_t stream) {
+  if (hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) != hipSuccess) {
+    hdiff::set_error("hipEventRecord failed");
+    return HDIFF_ERR_LAUNCH;
+  }
+  return HDIFF_OK;
+}
+int hdiff_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess ||
+      hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) {
+    hdiff::set_error("hipEventElapsedTime failed");
+    return HDIFF_ERR_LAUNCH;
+  }
+  return HDIFF_OK;
+}
+int hdiff_event_destroy(void* ev) {
+  if (ev) hipEventDestroy((hipEvent_t)ev);
+  return HDIFF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,268 @@
+// Small dense layers, the DDPM elementwise steps and the in-graph normal generator (gfx950).
+// All HBM- or latency-bound; none of them shows up next to attention/conv at the target sizes, so they are written
+// for clarity: one wave per output of a GEMV, 16-byte grid-stride loops for the elementwise passes.
+#include "common.h"
+
+// The DDPM elementwise steps must round exactly like the reference's separate mul / sub / add tensor ops:
+// fma contraction is forbidden in this file (hipcc defaults to -ffp-contract=fast for device code, and HIP's __fmul_rn
+// is a plain, contractible '*'): the Makefile compiles it with -ffp-contract=off and the pragma repeats it.
+#pragma clang fp contract(off)
+
+using namespace hdiff;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// y[b][j] (+)= bias[j] + sum_k W[j][k] * f(x_row(b)[k]); one wave per (b, j).
+// Reference: nn.Embedding gather + nn.Linear (+Swish on the input) at ModelCondition.py:38-43, 56-61, 174-181.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void linear_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                   const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ y,
+                                   int B, int K, int N, int n_rows, int swish_input, int accumulate) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= B * N) return;
+  const int b = wave / N, j = wave - b * N;
+  int64_t row = idx ? idx[b] : (int64_t)b;
+  if (idx && n_rows > 0) row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);   // never fault on a bad index; the host validates
+  const float* xr = x + (size_t)row * K;
+  const float* wr = W + (size_t)j * K;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    float v = xr[k];
+    if (swish_input) v = swishf(v);
+    s = fmaf(wr[k], v, s);
+  }
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (bias) s += bias[j];
+    y[(size_t)b * N + j] = accumulate ? y[(size_t)b * N + j] + s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator + Box-Muller: 4 normals per counter.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi, (uint32_t)(ctr_hi >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__device__ __forceinline__ float4 normal4(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi) {
+  uint32_t r[4];
+  philox4x32_10(seed, ctr_lo, ctr_hi, r);
+  // u in (0,1]: (r + 1) * 2^-32 ; Box-Muller on two pairs
+  const float u0 = ((float)(r[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u1 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(r[2] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u3 = ((float)(r[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u1, &s0, &c0);
+  sincosf(6.283185307179586f * u3, &s1, &c1);
+  return make_float4(ra * c0, ra * s0, rb * c1, rb * s1);
+}
+
+__global__ void randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  const int64_t nq = (n + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const float4 z = normal4(seed, (uint64_t)q, offset);
+    const int64_t i = q << 2;
+    if (i + 3 < n) {
+      *reinterpret_cast<float4*>(out + i) = z;
+    } else {
+      const float zz[4] = {z.x, z.y, z.z, z.w};
+      for (int e = 0; e < 4 && i + e < n; ++e) out[i + e] = zz[e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Diffusion elementwise steps (DiffusionCondition.py)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                const int64_t* __restrict__ t, const float* __restrict__ sa,
+                                const float* __restrict__ sb, float* __restrict__ xt, int per_sample) {
+  const int b = blockIdx.y;
+  const float a = sa[t[b]], c = sb[t[b]];
+  const size_t base = (size_t)b * per_sample;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += gridDim.x * blockDim.x)
+    xt[base + i] = a * x0[base + i] + c * noise[base + i];   // mul, mul, add: the reference's roundings (contraction is off)
+}
+
+__global__ void sq_err_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                              int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    out[i] = d * d;
+  }
+}
+
+// x_next = coeff1[t]*x - coeff2[t]*((1+w)*eps_c - w*eps_u) + sigma[t]*z   (DiffusionCondition.py:78-79, 95)
+// Written with separate multiplies/adds in the reference's order (no fma contraction across terms) so that the CPU
+// oracle and this kernel round identically given identical eps.
+__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_c,
+                                 const float* __restrict__ eps_u, const float* __restrict__ noise,
+                                 float* __restrict__ x_next, const float* __restrict__ coeff1,
+                                 const float* __restrict__ coeff2, const float* __restrict__ sigma,
+                                 const int32_t* __restrict__ step_ptr, float w1, float w, uint64_t seed,
+                                 int32_t* __restrict__ nan_flag, int64_t n) {
+  const int step = *step_ptr;
+  const float c1 = coeff1[step], c2 = coeff2[step], sg = sigma[step];
+  const bool add_noise = step > 0;
+  bool bad = false;
+  const int64_t nq = (n + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = q << 2;
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (add_noise && noise == nullptr) {
+      const float4 zz = normal4(seed, (uint64_t)q, (uint64_t)(uint32_t)step);
+      z[0] = zz.x; z[1] = zz.y; z[2] = zz.z; z[3] = zz.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = i0 + e;
+      if (i < n) {
+        if (add_noise && noise != nullptr) z[e] = noise[i];
+        const float eps = w1 * eps_c[i] - w * eps_u[i];
+        const float mean = c1 * x[i] - c2 * eps;
+        const float v = add_noise ? mean + sg * z[e] : mean;
+        bad |= (v != v);
+        x_next[i] = v;
+      }
+    }
+  }
+  if (__any(bad)) {
+    if ((threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+  }
+}
+
+__global__ void fill_t_kernel(int64_t* t, const int32_t* step_ptr, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) t[i] = (int64_t)(*step_ptr);
+}
+__global__ void step_decrement_kernel(int32_t* step_ptr) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr = *step_ptr - 1;
+}
+__global__ void clip_kernel(const float* __restrict__ x, float* __restrict__ y, float lo, float hi, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = fminf(fmaxf(x[i], lo), hi);
+}
+__global__ void axpby_kernel(float a, const float* __restrict__ x, float b, const float* __restrict__ y,
+                             float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = y ? a * x[i] + b * y[i] : a * x[i];   // separate roundings (mul, mul, add): contraction is off in this file
+}
+
+inline int grid_for(int64_t n, int per_thread = 1) {
+  int64_t blocks = (n / per_thread + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hdiff_linear_rows(const float* x, const int64_t* idx, int n_rows, const float* W, const float* bias, float* y, int B,
+                      int K, int N, int swish_input, int accumulate, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(x && W && y, "linear_rows: null pointer");
+  HDIFF_CHECK_ARG(B > 0 && K > 0 && N > 0, "linear_rows: bad sizes");
+  const int waves = B * N;
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(linear_rows_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, idx, W, bias, y, B,
+                     K, N, n_rows, swish_input, accumulate);
+  HDIFF_CHECK_LAUNCH("linear_rows_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ab, const float* sqrt_1mab,
+                   float* xt, int B, int per_sample, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(x0 && noise && t && sqrt_ab && sqrt_1mab && xt, "q_sample: null pointer");
+  const int bx = cdiv(per_sample, 256) < 256 ? cdiv(per_sample, 256) : 256;
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(q_sample_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, x0, noise, t, sqrt_ab, sqrt_1mab,
+                     xt, per_sample);
+  HDIFF_CHECK_LAUNCH("q_sample_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_sq_err(const float* a, const float* b, float* out, int64_t n, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(a && b && out, "sq_err: null pointer");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(sq_err_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  HDIFF_CHECK_LAUNCH("sq_err_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_ddpm_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, float* x_next,
+                    const float* coeff1, const float* coeff2, const float* sigma, const int32_t* step_ptr, double w,
+                    uint64_t seed, int32_t* nan_flag, int64_t n, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(x && eps_c && eps_u && x_next && coeff1 && coeff2 && sigma && step_ptr && nan_flag,
+                  "ddpm_step: null pointer");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, x, eps_c, eps_u, noise,
+                     x_next, coeff1, coeff2, sigma, step_ptr, (float)(1.0 + w), (float)w, seed, nan_flag, n);
+  HDIFF_CHECK_LAUNCH("ddpm_step_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_fill_t(int64_t* t, const int32_t* step_ptr, int B, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(t && step_ptr && B > 0, "fill_t: bad arguments");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(fill_t_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, t, step_ptr, B);
+  HDIFF_CHECK_LAUNCH("fill_t_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_step_decrement(int32_t* step_ptr, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(step_ptr, "step_decrement: null pointer");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(step_decrement_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_ptr);
+  HDIFF_CHECK_LAUNCH("step_decrement_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_clip(const float* x, float* y, float lo, float hi, int64_t n, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(x && y, "clip: null pointer");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(clip_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, lo, hi, n);
+  HDIFF_CHECK_LAUNCH("clip_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(out, "randn: null pointer");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(randn_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
+  HDIFF_CHECK_LAUNCH("randn_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_axpby(float a, const float* x, float b, const float* y, float* out, int64_t n, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(x && out, "axpby: null pointer");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, x, b, y, out, n);
+  HDIFF_CHECK_LAUNCH("axpby_kernel");
+  return HDIFF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,431 @@
+"""Host-side launch planner for the HIP kernels of the CFG-DDPM hot path.
+
+PyTorch is used here only for device memory (``torch.empty``), streams and parameter storage.  All arithmetic is issued
+through the C ABI of ``libhdiff.so`` (``include/hdiff.h``).  A :class:`Plan` is a static list of C-ABI launches over
+preallocated buffers -- no allocation or synchronisation while it runs -- so a plan can be captured into a hipGraph
+(``Plan.capture``) and replayed, which is how the T-step sampler loop runs (reference loop: DiffusionCondition.py:87-96).
+
+The UNet emitter walks the architecture of the reference's ``UNet`` (ModelCondition.py:213-276) and maps it to launches:
+
+  ResBlock (ModelCondition.py:196-211)          launches
+    GroupNorm+Swish+Conv3x3 (+temb +cemb)   ->  gn_stats, gn_finalize, 2x linear_rows, conv(prologue=GN/Swish, epilogue=+bias+vec)
+    GroupNorm+Swish+Dropout+Conv3x3 + shortcut -> gn_stats, gn_finalize, [conv1x1 shortcut], conv(prologue, epilogue=+residual)
+    MultiheadAttention                      ->  conv1x1 (packed in-proj) -> mha_flash_fwd -> conv1x1 (out-proj)
+  DownSample (:74-76)  c1(x)+c2(x)          ->  ONE 5x5/s2 conv: the 3x3 weights are folded into the 5x5 centre at pack time
+  UpSample (:85-89)    ConvTranspose 5x5/s2 ->  4 output-parity phases (3x3, 3x2, 2x3, 2x2 taps) as stride-1 convs, then conv3x3
+  torch.cat skip (:271)                     ->  never materialised: consumers read two source pointers
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _capi
+
+GN_GROUPS = 32      # ModelCondition.py:170,184,249
+GN_EPS = 1e-5
+NUM_HEADS = 8       # ModelCondition.py:189
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _pad(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"hdiff: '{name}' lives on {t.device}; the HIP path needs an MI355X device tensor "
+                           "(there is deliberately no CPU fallback)")
+    if t.dtype != torch.float32 and t.dtype != torch.int64 and t.dtype != torch.int32:
+        raise RuntimeError(f"hdiff: '{name}' has dtype {t.dtype}; the path computes in fp32 with int64 indices")
+    if not t.is_contiguous():
+        raise RuntimeError(f"hdiff: '{name}' must be contiguous (NCHW)")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Packed convolution weights
+# ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class TapSet:
+    dy: List[int]
+    dx: List[int]
+    ky: List[int]      # kernel element feeding each tap (pack time)
+    kx: List[int]
+
+
+def conv_taps(k: int, pad: int) -> TapSet:
+    ys = [ky for ky in range(k) for _ in range(k)]
+    xs = [kx for _ in range(k) for kx in range(k)]
+    return TapSet([y - pad for y in ys], [x - pad for x in xs], ys, xs)
+
+
+def tconv_phase_taps(py: int, px: int) -> TapSet:
+    """ConvTranspose2d(5, stride 2, pad 2, out_pad 1): output (2y+py, 2x+px) gathers x[y+dy][x+dx]*w[ky][kx] with
+    ky = py + 2 - 2*dy (ModelCondition.py:83; oy = 2*iy - 2 + ky)."""
+    kys = [ky for ky in range(5) if (ky - py) % 2 == 0]
+    kxs = [kx for kx in range(5) if (kx - px) % 2 == 0]
+    t = TapSet([], [], [], [])
+    for ky in kys:
+        for kx in kxs:
+            t.dy.append((py + 2 - ky) // 2)
+            t.dx.append((px + 2 - kx) // 2)
+            t.ky.append(ky)
+            t.kx.append(kx)
+    return t
+
+
+class PackedConv:
+    """Device-side packed weights wp[tap][CinPad][CoutPad] for one convolution launch (conv_igemm.hip)."""
+
+    def __init__(self, device, cout: int, cin: int, taps: TapSet):
+        self.cout, self.cin, self.taps = cout, cin, taps
+        self.cin_pad, self.cout_pad = _pad(cin, 8), _pad(cout, 64)
+        self.ntaps = len(taps.dy)
+        self.wp = torch.empty(self.ntaps * self.cin_pad * self.cout_pad, dtype=torch.float32, device=device)
+        self.sources: List[Tuple[torch.Tensor, int, int, int, List[int], List[int], int]] = []
+
+    def add_source(self, w: torch.Tensor, mode: int, ky: Sequence[int], kx: Sequence[int], accumulate: int) -> None:
+        kh, kw = int(w.shape[2]), int(w.shape[3])
+        self.sources.append((w, mode, kh, kw, list(ky), list(kx), accumulate))
+
+    def pack(self, stream: int) -> None:
+        lib = _capi.lib()
+        for w, mode, kh, kw, ky, kx, acc in self.sources:
+            require_gpu_tensor(w, "conv weight")
+            a_ky = (C.c_int * self.ntaps)(*ky)
+            a_kx = (C.c_int * self.ntaps)(*kx)
+            _capi.check(lib.hdiff_pack_conv_weight(w.data_ptr(), self.wp.data_ptr(), mode, self.cout, self.cin, kh, kw,
+                                                   self.ntaps, a_ky, a_kx, self.cin_pad, self.cout_pad, acc, stream),
+                        "pack_conv_weight")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Plan
+# ----------------------------------------------------------------------------------------------------------------------
+class Plan:
+    """A static, replayable list of C-ABI launches over preallocated device buffers."""
+
+    def __init__(self, device: torch.device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("hdiff: plans run on an MI355X device only (no CPU fallback)")
+        self.lib = _capi.lib()
+        self.ops: List[Tuple[str, Callable, tuple]] = []
+        self.packs: List[PackedConv] = []
+        self._pool: Dict[int, List[torch.Tensor]] = {}
+        self._all: List[torch.Tensor] = []
+        self._keep: List[object] = []
+        self.graph = C.c_void_p(None)
+        self._graph_stream: Optional[torch.cuda.Stream] = None
+
+    # -- memory -------------------------------------------------------------------------------------------------------
+    def buf(self, *shape: int, dtype=torch.float32) -> torch.Tensor:
+        n = 1
+        for s in shape:
+            n *= int(s)
+        key = n * (8 if dtype == torch.int64 else 4)
+        free = self._pool.get(key)
+        if free:
+            base = free.pop()
+        else:
+            base = torch.empty(key // 4, dtype=torch.float32, device=self.device)
+            self._all.append(base)
+        t = base.view(dtype)[:n].view(*shape) if dtype != torch.float32 else base[:n].view(*shape)
+        t._hdiff_base = base  # type: ignore[attr-defined]
+        return t
+
+    def free(self, t: torch.Tensor) -> None:
+        base = getattr(t, "_hdiff_base", None)
+        if base is not None:
+            self._pool.setdefault(base.numel() * 4, []).append(base)
+
+    def bytes_allocated(self) -> int:
+        return sum(b.numel() * 4 for b in self._all)
+
+    # -- launches -----------------------------------------------------------------------------------------------------
+    def call(self, name: str, *args) -> None:
+        self.ops.append((name, getattr(self.lib, name), args))
+
+    def keep(self, obj) -> None:
+        self._keep.append(obj)
+
+    def run(self, stream: Optional[int] = None) -> None:
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        for name, fn, args in self.ops:
+            rc = fn(*args, s)
+            if rc != 0:
+                _capi.check(rc, name)
+
+    def pack_weights(self, stream: Optional[int] = None) -> None:
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        for p in self.packs:
+            p.pack(s)
+
+    # -- hipGraph -----------------------------------------------------------------------------------------------------
+    def capture(self) -> None:
+        """Capture the launch list into a hipGraph on a private stream (weights must already be packed)."""
+        if self.graph.value:
+            return
+        torch.cuda.synchronize(self.device)
+        self._graph_stream = torch.cuda.Stream(self.device)
+        s = self._graph_stream.cuda_stream
+        _capi.check(self.lib.hdiff_graph_begin(s), "graph_begin")
+        try:
+            self.run(s)
+        finally:
+            rc = self.lib.hdiff_graph_end(s, C.byref(self.graph))
+        _capi.check(rc, "graph_end")
+
+    def replay(self, stream: Optional[int] = None) -> None:
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        _capi.check(self.lib.hdiff_graph_launch(self.graph, s), "graph_launch")
+
+    def __del__(self):
+        try:
+            if self.graph.value:
+                self.lib.hdiff_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+    # -- op emitters --------------------------------------------------------------------------------------------------
+    def conv(self, x0: torch.Tensor, x1: Optional[torch.Tensor], pk: PackedConv, bias: Optional[torch.Tensor],
+             out: torch.Tensor, *, B: int, H: int, W: int, VH: int, VW: int, in_stride: int = 1,
+             out_map: Tuple[int, int, int, int] = (1, 0, 1, 0), gn: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+             addvec: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> None:
+        d = _capi.ConvDesc()
+        C0 = int(x0.shape[1])
+        C1 = int(x1.shape[1]) if x1 is not None else 0
+        assert C0 + C1 == pk.cin, (C0, C1, pk.cin)
+        d.x0, d.x1, d.C0, d.C1 = _ptr(x0), _ptr(x1), C0, C1
+        d.B, d.H, d.W = B, H, W
+        d.wp, d.bias = pk.wp.data_ptr(), _ptr(bias)
+        d.Cout, d.CinPad, d.CoutPad = pk.cout, pk.cin_pad, pk.cout_pad
+        d.gn_scale, d.gn_shift = (_ptr(gn[0]), _ptr(gn[1])) if gn is not None else (None, None)
+        d.addvec, d.residual, d.out = _ptr(addvec), _ptr(residual), out.data_ptr()
+        d.OH, d.OW = int(out.shape[2]), int(out.shape[3])
+        d.VH, d.VW, d.in_stride = VH, VW, in_stride
+        d.out_sy, d.out_oy, d.out_sx, d.out_ox = out_map
+        d.ntaps = pk.ntaps
+        for i in range(pk.ntaps):
+            d.tap_dy[i], d.tap_dx[i] = pk.taps.dy[i], pk.taps.dx[i]
+        self.keep((d, x0, x1, pk, bias, out, gn, addvec, residual))
+        self.call("hdiff_conv2d_fwd", C.byref(d))
+
+    def gn_scale_shift(self, x0: torch.Tensor, x1: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                       B: int, HW: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        C0 = int(x0.shape[1])
+        C1 = int(x1.shape[1]) if x1 is not None else 0
+        Ct = C0 + C1
+        if Ct % GN_GROUPS != 0:
+            raise RuntimeError(f"Expected number of channels in input to be divisible by num_groups, got {Ct}")
+        # enough workgroups to stream at HBM rate, but at least ~4K elements per slice
+        nsplit = max(1, min(64, 1024 // (B * GN_GROUPS), HW // 1024))
+        ws = self.buf(B * GN_GROUPS * nsplit * 3)
+        scale, shift = self.buf(B, Ct), self.buf(B, Ct)
+        self.call("hdiff_gn_stats", _ptr(x0), _ptr(x1), C0, C1, B, HW, GN_GROUPS, nsplit, ws.data_ptr())
+        self.call("hdiff_gn_finalize", ws.data_ptr(), B, Ct, GN_GROUPS, nsplit, gamma.data_ptr(), beta.data_ptr(),
+                  C.c_float(GN_EPS), scale.data_ptr(), shift.data_ptr(), None, None)
+        self.keep((x0, x1, gamma, beta, ws))
+        self.free(ws)
+        return scale, shift
+
+    def linear(self, x: torch.Tensor, idx: Optional[torch.Tensor], W: torch.Tensor, bias: Optional[torch.Tensor],
+               y: torch.Tensor, B: int, swish_input: bool, accumulate: bool) -> None:
+        N, K = int(W.shape[0]), int(W.shape[1])
+        self.keep((x, idx, W, bias, y))
+        n_rows = int(x.shape[0]) if idx is not None else 0
+        self.call("hdiff_linear_rows", x.data_ptr(), _ptr(idx), n_rows, W.data_ptr(), _ptr(bias), y.data_ptr(), B, K, N,
+                  int(swish_input), int(accumulate))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# UNet emitter
+# ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class UNetShape:
+    T: int
+    num_labels: int
+    ch: int
+    ch_mult: Tuple[int, ...]
+    num_res_blocks: int
+
+
+def _new_pack(plan: Plan, cout: int, cin: int, taps: TapSet) -> PackedConv:
+    pk = PackedConv(plan.device, cout, cin, taps)
+    plan.packs.append(pk)
+    return pk
+
+
+def _std_pack(plan: Plan, w: torch.Tensor, k: int, pad: int) -> PackedConv:
+    taps = conv_taps(k, pad)
+    pk = _new_pack(plan, int(w.shape[0]), int(w.shape[1]), taps)
+    pk.add_source(w, 0, taps.ky, taps.kx, 0)
+    return pk
+
+
+def emit_embed_mlp(plan: Plan, P: Dict[str, torch.Tensor], prefix: str, idx: torch.Tensor, B: int) -> torch.Tensor:
+    """Embedding -> Linear -> Swish -> Linear (ModelCondition.py:38-49, 56-65)."""
+    w1, b1, w2, b2 = P[f"{prefix}.1.weight"], P[f"{prefix}.1.bias"], P[f"{prefix}.3.weight"], P[f"{prefix}.3.bias"]
+    h = plan.buf(B, int(w1.shape[0]))
+    out = plan.buf(B, int(w2.shape[0]))
+    plan.linear(P[f"{prefix}.0.weight"], idx, w1, b1, h, B, swish_input=False, accumulate=False)
+    plan.linear(h, None, w2, b2, out, B, swish_input=True, accumulate=False)
+    plan.free(h)
+    return out
+
+
+def emit_mha(plan: Plan, P: Dict[str, torch.Tensor], p: str, h: torch.Tensor, B: int, Cc: int, H: int, W: int) -> torch.Tensor:
+    """nn.MultiheadAttention(C, 8) as attn(h,h,h) on (L,B,C): no pre-norm, no residual (ModelCondition.py:204-208)."""
+    if Cc % NUM_HEADS != 0:
+        raise AssertionError("embed_dim must be divisible by num_heads")
+    w_in = P[f"{p}.attn.in_proj_weight"].view(3 * Cc, Cc, 1, 1)
+    w_out = P[f"{p}.attn.out_proj.weight"].view(Cc, Cc, 1, 1)
+    pk_in, pk_out = _std_pack(plan, w_in, 1, 0), _std_pack(plan, w_out, 1, 0)
+    qkv = plan.buf(B, 3 * Cc, H, W)
+    plan.conv(h, None, pk_in, P[f"{p}.attn.in_proj_bias"], qkv, B=B, H=H, W=W, VH=H, VW=W)
+    o = plan.buf(B, Cc, H, W)
+    plan.call("hdiff_mha_flash_fwd", qkv.data_ptr(), o.data_ptr(), B, Cc, NUM_HEADS, H * W)
+    plan.keep((qkv, o))
+    plan.free(qkv)
+    y = plan.buf(B, Cc, H, W)
+    plan.conv(o, None, pk_out, P[f"{p}.attn.out_proj.bias"], y, B=B, H=H, W=W, VH=H, VW=W)
+    plan.free(o)
+    return y
+
+
+def emit_resblock(plan: Plan, P: Dict[str, torch.Tensor], p: str, xa: torch.Tensor, xb: Optional[torch.Tensor],
+                  temb: torch.Tensor, cemb: Optional[torch.Tensor], cout: int, B: int, H: int, W: int, attn: bool) -> torch.Tensor:
+    """ResBlock.forward (ModelCondition.py:196-211) on the virtual concat [xa | xb]."""
+    sc1 = plan.gn_scale_shift(xa, xb, P[f"{p}.block1.0.weight"], P[f"{p}.block1.0.bias"], B, H * W)
+    vec = plan.buf(B, cout)
+    plan.linear(temb, None, P[f"{p}.temb_proj.1.weight"], P[f"{p}.temb_proj.1.bias"], vec, B, True, False)
+    if cemb is not None:
+        plan.linear(cemb, None, P[f"{p}.cond_proj.1.weight"], P[f"{p}.cond_proj.1.bias"], vec, B, True, True)
+    pk1 = _std_pack(plan, P[f"{p}.block1.2.weight"], 3, 1)
+    h1 = plan.buf(B, cout, H, W)
+    plan.conv(xa, xb, pk1, P[f"{p}.block1.2.bias"], h1, B=B, H=H, W=W, VH=H, VW=W, gn=sc1, addvec=vec)
+    plan.free(sc1[0]); plan.free(sc1[1]); plan.free(vec)
+
+    sc2 = plan.gn_scale_shift(h1, None, P[f"{p}.block2.0.weight"], P[f"{p}.block2.0.bias"], B, H * W)
+    if f"{p}.shortcut.weight" in P:
+        pks = _std_pack(plan, P[f"{p}.shortcut.weight"], 1, 0)
+        res = plan.buf(B, cout, H, W)
+        plan.conv(xa, xb, pks, P[f"{p}.shortcut.bias"], res, B=B, H=H, W=W, VH=H, VW=W)
+        res_owned = True
+    else:
+        assert xb is None
+        res, res_owned = xa, False
+    pk2 = _std_pack(plan, P[f"{p}.block2.3.weight"], 3, 1)
+    h2 = plan.buf(B, cout, H, W)
+    plan.conv(h1, None, pk2, P[f"{p}.block2.3.bias"], h2, B=B, H=H, W=W, VH=H, VW=W, gn=sc2, residual=res)
+    plan.free(sc2[0]); plan.free(sc2[1]); plan.free(h1)
+    if res_owned:
+        plan.free(res)
+    if attn:
+        y = emit_mha(plan, P, p, h2, B, cout, H, W)
+        plan.free(h2)
+        return y
+    return h2
+
+
+def emit_downsample(plan: Plan, P: Dict[str, torch.Tensor], p: str, x: torch.Tensor, B: int, Cc: int, H: int, W: int) -> torch.Tensor:
+    """DownSample.forward (ModelCondition.py:74-76): c1(x) + c2(x) as one 5x5/s2 conv with folded weights and biases."""
+    taps = conv_taps(5, 2)
+    pk = _new_pack(plan, Cc, Cc, taps)
+    pk.add_source(P[f"{p}.c2.weight"], 0, taps.ky, taps.kx, 0)
+    ky3 = [ky - 1 if (1 <= ky <= 3 and 1 <= kx <= 3) else -1 for ky, kx in zip(taps.ky, taps.kx)]
+    kx3 = [kx - 1 if (1 <= ky <= 3 and 1 <= kx <= 3) else 0 for ky, kx in zip(taps.ky, taps.kx)]
+    pk.add_source(P[f"{p}.c1.weight"], 0, ky3, kx3, 1)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    bias = plan.buf(Cc)
+    plan.call("hdiff_axpby", C.c_float(1.0), P[f"{p}.c1.bias"].data_ptr(), C.c_float(1.0), P[f"{p}.c2.bias"].data_ptr(),
+              bias.data_ptr(), Cc)
+    plan.keep((P[f"{p}.c1.bias"], P[f"{p}.c2.bias"]))
+    y = plan.buf(B, Cc, OH, OW)
+    plan.conv(x, None, pk, bias, y, B=B, H=H, W=W, VH=OH, VW=OW, in_stride=2)
+    plan.free(bias)
+    return y
+
+
+def emit_upsample(plan: Plan, P: Dict[str, torch.Tensor], p: str, x: torch.Tensor, B: int, Cc: int, H: int, W: int) -> torch.Tensor:
+    """UpSample.forward (ModelCondition.py:85-89): ConvTranspose2d(5,2,2,1) as 4 parity phases, then Conv3x3."""
+    wt = P[f"{p}.t.weight"]                      # [Cin][Cout][5][5]
+    u = plan.buf(B, Cc, 2 * H, 2 * W)
+    for py in (0, 1):
+        for px in (0, 1):
+            taps = tconv_phase_taps(py, px)
+            pk = _new_pack(plan, Cc, Cc, taps)
+            pk.add_source(wt, 1, taps.ky, taps.kx, 0)
+            plan.conv(x, None, pk, P[f"{p}.t.bias"], u, B=B, H=H, W=W, VH=H, VW=W, out_map=(2, py, 2, px))
+    pkc = _std_pack(plan, P[f"{p}.c.weight"], 3, 1)
+    y = plan.buf(B, Cc, 2 * H, 2 * W)
+    plan.conv(u, None, pkc, P[f"{p}.c.bias"], y, B=B, H=2 * H, W=2 * W, VH=2 * H, VW=2 * W)
+    plan.free(u)
+    return y
+
+
+class UNetPlan:
+    """Launch plan of one UNet.forward (ModelCondition.py:255-276) for a fixed (B, H, W)."""
+
+    def __init__(self, P: Dict[str, torch.Tensor], shape: UNetShape, B: int, H: int, W: int, device):
+        if H % (2 ** (len(shape.ch_mult) - 1)) or W % (2 ** (len(shape.ch_mult) - 1)):
+            # the reference fails at the skip concat (ModelCondition.py:271) for such sizes
+            raise RuntimeError(f"Sizes of tensors must match: H, W = {H}, {W} not divisible by "
+                               f"{2 ** (len(shape.ch_mult) - 1)}")
+        plan = Plan(device)
+        self.plan, self.B, self.H, self.W = plan, B, H, W
+        self.x = plan.buf(B, 3, H, W)
+        self.t = plan.buf(B, dtype=torch.int64)
+        self.labels = plan.buf(B, dtype=torch.int64)
+        ch = shape.ch
+        temb = emit_embed_mlp(plan, P, "time_embedding.timembedding", self.t, B)
+        cemb = emit_embed_mlp(plan, P, "cond_embedding.condEmbedding", self.labels, B)
+
+        pk_head = _std_pack(plan, P["head.weight"], 3, 1)
+        h = plan.buf(B, ch, H, W)
+        plan.conv(self.x, None, pk_head, P["head.bias"], h, B=B, H=H, W=W, VH=H, VW=W)
+        hs: List[Tuple[torch.Tensor, int, int, int]] = [(h, ch, H, W)]
+        now, cH, cW = ch, H, W
+        n_down = 0
+        for i, mult in enumerate(shape.ch_mult):
+            out = ch * mult
+            for _ in range(shape.num_res_blocks):
+                h = emit_resblock(plan, P, f"downblocks.{n_down}", h, None, temb, cemb, out, B, cH, cW, attn=True)
+                n_down += 1
+                now = out
+                hs.append((h, now, cH, cW))
+            if i != len(shape.ch_mult) - 1:
+                h = emit_downsample(plan, P, f"downblocks.{n_down}", h, B, now, cH, cW)
+                n_down += 1
+                cH, cW = (cH - 1) // 2 + 1, (cW - 1) // 2 + 1
+                hs.append((h, now, cH, cW))
+        hm = emit_resblock(plan, P, "middleblocks.0", h, None, temb, cemb, now, B, cH, cW, attn=True)
+        h = emit_resblock(plan, P, "middleblocks.1", hm, None, temb, cemb, now, B, cH, cW, attn=False)
+        plan.free(hm)
+        n_up = 0
+        for i, mult in reversed(list(enumerate(shape.ch_mult))):
+            out = ch * mult
+            for _ in range(shape.num_res_blocks + 1):
+                skip, sc, sH, sW = hs.pop()
+                assert (sH, sW) == (cH, cW)
+                y = emit_resblock(plan, P, f"upblocks.{n_up}", h, skip, temb, cemb, out, B, cH, cW, attn=False)
+                n_up += 1
+                plan.free(h); plan.free(skip)
+                h, now = y, out
+            if i != 0:
+                y = emit_upsample(plan, P, f"upblocks.{n_up}", h, B, now, cH, cW)
+                n_up += 1
+                plan.free(h)
+                h, cH, cW = y, 2 * cH, 2 * cW
+        assert not hs
+        sct = plan.gn_scale_shift(h, None, P["tail.0.weight"], P["tail.0.bias"], B, cH * cW)
+        pk_tail = _std_pack(plan, P["tail.2.weight"], 3, 1)
+        self.out = plan.buf(B, 3, H, W)
+        plan.conv(h, None, pk_tail, P["tail.2.bias"], self.out, B=B, H=H, W=W, VH=H, VW=W, gn=sct)
+        plan.keep((temb, cemb, h))

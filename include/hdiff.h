@@ -1,0 +1,161 @@
+/*
+ * hdiff.h -- C ABI of the MI355X (gfx950) CFG-DDPM hot path.
+ *
+ * One shared library (libhdiff.so, built from hybrid-diffusion-underwater-atmopheric-image-enhancement_amd/csrc)
+ * exports every operator the reference's hot path calls through PyTorch.  The reference
+ * has no FFI of its own for this path: its "operator interface" is the set of ATen call sites listed beside each entry
+ * point below (paths relative to the reference checkout).  All entry points
+ *   - take plain device pointers, sizes and a HIP stream (void* = hipStream_t); no torch types,
+ *   - are stream-ordered and stateless (no allocation, no synchronisation: safe under hipGraph capture),
+ *   - return 0 on success or a negative hdiff_status; hdiff_last_error() gives the text,
+ *   - compute in fp32 (fp32-input MFMA for every contraction); tensors are fp32 NCHW contiguous, indices int64.
+ */
+#ifndef HDIFF_H_
+#define HDIFF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hdiff_stream_t; /* hipStream_t */
+
+enum hdiff_status {
+  HDIFF_OK = 0,
+  HDIFF_ERR_INVALID = -1,  /* bad shape / unsupported configuration */
+  HDIFF_ERR_LAUNCH = -2,   /* HIP launch error */
+  HDIFF_ERR_NO_DEVICE = -3
+};
+
+int hdiff_abi_version(void);
+const char* hdiff_last_error(void);
+/* Number of HIP devices visible (0 without a GPU); never initialises a context. */
+int hdiff_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Convolutions (K1-K4).  Replaces nn.Conv2d / nn.ConvTranspose2d call sites
+ *   DiffusionFreeGuidence/ModelCondition.py:71-75 (DownSample), :82-88 (UpSample), :172,:186,:192 (ResBlock),
+ *   :219 (head), :251 (tail) and the packed in/out projections of nn.MultiheadAttention (:189) viewed as 1x1 convs.
+ *
+ * Weights are consumed in a packed layout wp[tap][CinPad][CoutPad] (CoutPad % 64 == 0, CinPad % 8 == 0, zero padded),
+ * produced on the device by hdiff_pack_conv_weight from the PyTorch layouts.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+#define HDIFF_MAX_TAPS 25
+
+/* mode 0: Conv2d weight [Cout][Cin][KH][KW]; mode 1: ConvTranspose2d weight [Cin][Cout][KH][KW].
+ * tap t of the packed tensor takes kernel element (tap_ky[t], tap_kx[t]).  accumulate != 0 adds into wp (used to fold
+ * DownSample's 3x3 into the centre of its 5x5: ModelCondition.py:75 computes c1(x)+c2(x) on the same input). */
+int hdiff_pack_conv_weight(const float* w, float* wp, int mode, int Cout, int Cin, int KH, int KW, int ntaps,
+                           const int* tap_ky, const int* tap_kx, int CinPad, int CoutPad, int accumulate,
+                           hdiff_stream_t stream);
+
+typedef struct hdiff_conv_desc {
+  /* input: virtual channel-concat of x0 [B][C0][H][W] and x1 [B][C1][H][W] (x1 may be NULL with C1 = 0);
+   * replaces torch.cat([h, hs.pop()], dim=1) at ModelCondition.py:271 */
+  const float* x0;
+  const float* x1;
+  int C0, C1;
+  int B, H, W;
+  /* packed weights and optional bias [Cout] */
+  const float* wp;
+  const float* bias;
+  int Cout, CinPad, CoutPad;
+  /* optional fused prologue: y = swish(x * gn_scale[b][c] + gn_shift[b][c])  (GroupNorm affine + Swish folded to a
+   * per-(sample,channel) scale/shift by hdiff_gn_finalize; zero padding is applied AFTER the activation) */
+  const float* gn_scale;
+  const float* gn_shift;
+  /* optional fused epilogue: + addvec[b][co] (temb/cemb projections, ModelCondition.py:198-200), + residual (h + shortcut(x), :202) */
+  const float* addvec;
+  const float* residual;
+  float* out;      /* [B][Cout][OH][OW] */
+  int OH, OW;
+  /* geometry: the kernel iterates a virtual output grid VH x VW; input coord = v*in_stride + tap_d; output coord = v*out_s + out_o */
+  int VH, VW;
+  int in_stride;
+  int out_sy, out_oy, out_sx, out_ox;
+  int ntaps;
+  int tap_dy[HDIFF_MAX_TAPS];
+  int tap_dx[HDIFF_MAX_TAPS];
+} hdiff_conv_desc;
+
+int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * GroupNorm statistics (K5).  Replaces nn.GroupNorm(32, C) at ModelCondition.py:170,184,249 (the normalisation itself
+ * and the Swish at :22-24 are applied inside the consuming convolution's prologue).
+ *   hdiff_gn_stats:    partial (count, mean, M2) per (sample, group, split) over the virtual concat input
+ *   hdiff_gn_finalize: combines the partials (Chan) and writes scale[b][c] = rstd*gamma[c], shift[b][c] = beta[c]-mean*scale
+ * ws must hold B*G*nsplit*3 floats.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int hdiff_gn_stats(const float* x0, const float* x1, int C0, int C1, int B, int HW, int G, int nsplit, float* ws,
+                   hdiff_stream_t stream);
+int hdiff_gn_finalize(const float* ws, int B, int C, int G, int nsplit, const float* gamma, const float* beta, float eps,
+                      float* scale, float* shift, float* mean_out /*[B][G] or NULL*/, float* rstd_out /*[B][G] or NULL*/,
+                      hdiff_stream_t stream);
+/* Stand-alone y = swish(x*scale+shift) (used by tests and by the training path). */
+int hdiff_gn_swish_apply(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
+                         hdiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-head self-attention core (K9).  Replaces the softmax(QK^T/sqrt(d))V of nn.MultiheadAttention(C, 8) called as
+ * attn(h,h,h) at ModelCondition.py:189,204-208.  qkv is the output of the packed in-projection viewed as a 1x1 conv:
+ * [B][3C][L] with rows [Q | K | V], head h owning rows h*d..h*d+d-1 of each third.  o is [B][C][L].
+ * Flash style: the L x L score matrix is never materialised.  d = C/heads must be one of 4, 8, 16, 32.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int hdiff_mha_flash_fwd(const float* qkv, float* o, int B, int C, int heads, int L, hdiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Small dense layers (K6, K10).  y[b][j] (+)= bias[j] + sum_k W[j][k] * f(x_row(b)[k]),  f = identity or Swish.
+ * If idx != NULL the input row is x[idx[b]] (nn.Embedding gather, ModelCondition.py:38,56) with idx clamped to
+ * [0, n_rows) so a bad index can never fault the GPU (the host layer raises IndexError like nn.Embedding); otherwise x[b].
+ * Replaces nn.Linear / nn.Embedding at ModelCondition.py:38-43, 56-61, 174-181.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int hdiff_linear_rows(const float* x, const int64_t* idx, int n_rows, const float* W, const float* bias, float* y, int B,
+                      int K, int N, int swish_input, int accumulate, hdiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Diffusion process (K11-K13), DiffusionFreeGuidence/DiffusionCondition.py.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* q_sample (:43-44): x_t = sa[t[b]]*x0 + sb[t[b]]*noise ; sa/sb are the fp32 casts of the float64 schedule buffers. */
+int hdiff_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ab, const float* sqrt_1mab,
+                   float* xt, int B, int per_sample, hdiff_stream_t stream);
+/* unreduced squared error (:45): loss = (eps_hat - noise)^2 */
+int hdiff_sq_err(const float* a, const float* b, float* out, int64_t n, hdiff_stream_t stream);
+/* One ancestral step (:74-80, :89-96):
+ *   eps = (1+w)*eps_c - w*eps_u  (w is the Python float of the reference; (1+w) is formed in double, then cast) ; mean = coeff1[t]*x - coeff2[t]*eps ; x_next = mean + sigma[t]*z  (z = 0 when t == 0)
+ * step_ptr points at the device-resident current time step (int32) so the launch is hipGraph-replayable; when
+ * noise == NULL z is drawn in-kernel (Philox4x32-10 + Box-Muller, counter = (seed, step, element)).  nan_flag (int32)
+ * is OR-ed with 1 if any output is NaN (the reference's per-step assert, :96, evaluated once after the loop). */
+int hdiff_ddpm_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, float* x_next,
+                    const float* coeff1, const float* coeff2, const float* sigma, const int32_t* step_ptr, double w,
+                    uint64_t seed, int32_t* nan_flag, int64_t n, hdiff_stream_t stream);
+/* step bookkeeping for the captured loop: t[b] = *step for all b (int64 vector for the embedding gather) */
+int hdiff_fill_t(int64_t* t, const int32_t* step_ptr, int B, hdiff_stream_t stream);
+int hdiff_step_decrement(int32_t* step_ptr, hdiff_stream_t stream);
+/* final clip (:98) */
+int hdiff_clip(const float* x, float* y, float lo, float hi, int64_t n, hdiff_stream_t stream);
+/* out = a*x + b*y (y may be NULL): bias merges and other weight-preparation arithmetic */
+int hdiff_axpby(float a, const float* x, float b, const float* y, float* out, int64_t n, hdiff_stream_t stream);
+/* standard-normal fill with the same Philox stream (used for in-graph noise and for tests of the generator) */
+int hdiff_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hdiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * hipGraph helpers: capture everything enqueued on `stream` between begin/end, replay it later.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int hdiff_graph_begin(hdiff_stream_t stream);
+int hdiff_graph_end(hdiff_stream_t stream, void** graph_exec_out);
+int hdiff_graph_launch(void* graph_exec, hdiff_stream_t stream);
+int hdiff_graph_destroy(void* graph_exec);
+
+/* HIP event timing on the launch stream (bench.py's roofline leg) */
+int hdiff_event_create(void** ev);
+int hdiff_event_record(void* ev, hdiff_stream_t stream);
+int hdiff_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+int hdiff_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDIFF_H_ */

@@ -1,0 +1,234 @@
+"""GPU parity, op level: every C-ABI kernel of libhdiff.so against the CPU oracle (oracle/cpu_path.py) on seeded inputs.
+
+Tolerances (fp32 path; exact-fp32 MFMA, so only summation order differs from the reference):
+  single op      <= 2e-5 * max|ref| (+1e-6)
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import hdiff_amd  # noqa: E402
+from hdiff_amd import _capi, engine as E  # noqa: E402
+from oracle import cpu_path as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def close(got, ref, rel=2e-5, abs_=1e-6, what=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    tol = rel * ref.abs().max().item() + abs_
+    assert err <= tol, f"{what}: max err {err:.3e} > tol {tol:.3e} (ref max {ref.abs().max().item():.3e})"
+
+
+def run_conv(x0, x1, w, b, k, pad, stride=1, gn=None, addvec=None, residual=None):
+    plan = E.Plan(DEV)
+    B, C0, H, W = x0.shape
+    pk = E._std_pack(plan, w.to(DEV), k, pad)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = plan.buf(B, w.shape[0], OH, OW)
+    dg = lambda t: None if t is None else t.to(DEV).contiguous()
+    plan.conv(dg(x0), dg(x1), pk, dg(b), out, B=B, H=H, W=W, VH=OH, VW=OW, in_stride=stride,
+              gn=None if gn is None else (dg(gn[0]), dg(gn[1])), addvec=dg(addvec), residual=dg(residual))
+    plan.pack_weights()
+    plan.run()
+    torch.cuda.synchronize()
+    return out.clone()
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B", [(3, 32, 16, 16, 2), (32, 3, 16, 16, 2), (128, 256, 8, 8, 1), (32, 64, 40, 24, 1),
+                                            (64, 64, 64, 64, 1), (128, 128, 32, 32, 2), (40, 72, 5, 7, 3)])
+def test_conv3x3_plain(cin, cout, H, W, B):
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    close(run_conv(x, None, w, b, 3, 1), F.conv2d(x, w, b, padding=1), what="conv3x3")
+
+
+def test_conv1x1_and_5x5_stride2():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 20, 12, generator=g)
+    w = torch.randn(96, 64, 1, 1, generator=g) / 8
+    b = torch.randn(96, generator=g)
+    close(run_conv(x, None, w, b, 1, 0), F.conv2d(x, w, b), what="conv1x1")
+    w5 = torch.randn(64, 64, 5, 5, generator=g) / 40
+    close(run_conv(x, None, w5, b[:64], 5, 2, stride=2), F.conv2d(x, w5, b[:64], stride=2, padding=2), what="conv5x5s2")
+    w3 = torch.randn(64, 64, 3, 3, generator=g) / 24
+    close(run_conv(x, None, w3, None, 3, 1, stride=2), F.conv2d(x, w3, None, stride=2, padding=1), what="conv3x3s2")
+
+
+def test_conv_fused_prologue_epilogue_concat():
+    g = torch.Generator().manual_seed(9)
+    B, C0, C1, Cout, H, W = 2, 64, 32, 64, 16, 16
+    xa, xb = torch.randn(B, C0, H, W, generator=g), torch.randn(B, C1, H, W, generator=g)
+    x = torch.cat([xa, xb], 1)
+    w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / 30
+    b = torch.randn(Cout, generator=g)
+    scale, shift = torch.rand(B, C0 + C1, generator=g) + 0.5, torch.randn(B, C0 + C1, generator=g)
+    addvec, res = torch.randn(B, Cout, generator=g), torch.randn(B, Cout, H, W, generator=g)
+    act = O.swish(x * scale[:, :, None, None] + shift[:, :, None, None])
+    ref = F.conv2d(act, w, b, padding=1) + addvec[:, :, None, None] + res
+    got = run_conv(xa, xb, w, b, 3, 1, gn=(scale, shift), addvec=addvec, residual=res)
+    close(got, ref, what="conv fused")
+
+
+@pytest.mark.parametrize("C0,C1,H,W,B", [(32, 0, 16, 16, 2), (256, 128, 8, 8, 2), (64, 0, 64, 64, 1), (96, 0, 6, 6, 2),
+                                         (128, 0, 128, 128, 1)])
+def test_groupnorm_scale_shift(C0, C1, H, W, B):
+    g = torch.Generator().manual_seed(C0 + C1 + H)
+    xa = torch.randn(B, C0, H, W, generator=g) * 2 + 0.7
+    xb = torch.randn(B, C1, H, W, generator=g) - 0.3 if C1 else None
+    Ct = C0 + C1
+    gamma, beta = torch.randn(Ct, generator=g), torch.randn(Ct, generator=g)
+    plan = E.Plan(DEV)
+    dg = lambda t: None if t is None else t.to(DEV)
+    sc, sh = plan.gn_scale_shift(dg(xa), dg(xb), dg(gamma), dg(beta), B, H * W)
+    plan.run()
+    x = xa if xb is None else torch.cat([xa, xb], 1)
+    mean, rstd = O.group_norm_stats(x, 32, 1e-5)
+    cpg = Ct // 32
+    ref_sc = rstd.repeat_interleave(cpg, 1) * gamma[None]
+    ref_sh = beta[None] - mean.repeat_interleave(cpg, 1) * ref_sc
+    close(sc, ref_sc, what="gn scale")
+    close(sh, ref_sh, rel=3e-5, what="gn shift")
+    # and the full GN+Swish through the stand-alone apply kernel
+    y = torch.empty(B, Ct, H, W, device=DEV)
+    lib = _capi.lib()
+    d_x = dg(x)
+    _capi.check(lib.hdiff_gn_swish_apply(d_x.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.data_ptr(), B, Ct, H * W,
+                                         torch.cuda.current_stream().cuda_stream))
+    close(y, O.swish(O.group_norm(x, 32, gamma, beta, 1e-5)), rel=3e-5, what="gn+swish")
+
+
+def attention_core_ref(qkv, heads):
+    B, C3, L = qkv.shape
+    Cc = C3 // 3
+    d = Cc // heads
+    q, k, v = [z.reshape(B, heads, d, L).transpose(2, 3).double() for z in qkv.split(Cc, dim=1)]
+    w = torch.softmax(q @ k.transpose(2, 3) / math.sqrt(d), dim=-1)
+    return (w @ v).transpose(2, 3).reshape(B, Cc, L).float()
+
+
+@pytest.mark.parametrize("d,L,B", [(4, 64, 2), (8, 256, 1), (16, 64, 2), (16, 1024, 1), (32, 36, 2), (32, 576, 1),
+                                   (16, 4096, 1), (32, 1000, 1), (8, 37, 1)])
+def test_flash_attention_core(d, L, B):
+    g = torch.Generator().manual_seed(d * 7 + L)
+    heads = 8
+    Cc = heads * d
+    qkv = torch.randn(B, 3 * Cc, L, generator=g) * 1.5
+    o = torch.empty(B, Cc, L, device=DEV)
+    lib = _capi.lib()
+    d_qkv = qkv.to(DEV)
+    _capi.check(lib.hdiff_mha_flash_fwd(d_qkv.data_ptr(), o.data_ptr(), B, Cc, heads, L,
+                                        torch.cuda.current_stream().cuda_stream), "mha")
+    torch.cuda.synchronize()
+    close(o, attention_core_ref(qkv, heads), rel=2e-5, abs_=2e-6, what=f"flash d={d} L={L}")
+
+
+def test_flash_attention_online_softmax_rescale():
+    """Force the running-max rescale: one key per later tile dominates (guide rule: test the rare branch)."""
+    g = torch.Generator().manual_seed(3)
+    heads, d, L, B = 8, 16, 512, 1
+    Cc = heads * d
+    qkv = torch.randn(B, 3 * Cc, L, generator=g)
+    qkv[:, Cc:2 * Cc, 70] *= 6.0      # spike keys in tile 1, 4 and 7
+    qkv[:, Cc:2 * Cc, 300] *= 12.0
+    qkv[:, Cc:2 * Cc, 500] *= 20.0
+    o = torch.empty(B, Cc, L, device=DEV)
+    d_qkv = qkv.to(DEV)
+    _capi.check(_capi.lib().hdiff_mha_flash_fwd(d_qkv.data_ptr(), o.data_ptr(), B, Cc, heads, L,
+                                                torch.cuda.current_stream().cuda_stream), "mha")
+    close(o, attention_core_ref(qkv, heads), rel=3e-5, abs_=3e-6, what="flash rescale")
+
+
+def test_linear_rows_and_gather():
+    g = torch.Generator().manual_seed(1)
+    table = torch.randn(20, 128, generator=g)
+    idx = torch.tensor([3, 0, 19, 7])
+    W1, b1 = torch.randn(512, 128, generator=g) / 11, torch.randn(512, generator=g)
+    y = torch.empty(4, 512, device=DEV)
+    lib, s = _capi.lib(), torch.cuda.current_stream().cuda_stream
+    # device copies are held in variables: a temporary's memory would be recycled before the kernel reads it
+    d_table, d_idx, d_W1, d_b1 = table.to(DEV), idx.to(DEV), W1.to(DEV), b1.to(DEV)
+    _capi.check(lib.hdiff_linear_rows(d_table.data_ptr(), d_idx.data_ptr(), 20, d_W1.data_ptr(), d_b1.data_ptr(),
+                                      y.data_ptr(), 4, 128, 512, 0, 0, s))
+    close(y, table[idx] @ W1.t() + b1, what="gather+linear")
+    x = torch.randn(4, 512, generator=g)
+    W2 = torch.randn(96, 512, generator=g) / 22
+    y2 = torch.ones(4, 96, device=DEV)
+    d_x, d_W2 = x.to(DEV), W2.to(DEV)
+    _capi.check(lib.hdiff_linear_rows(d_x.data_ptr(), None, 0, d_W2.data_ptr(), None, y2.data_ptr(), 4, 512, 96, 1, 1, s))
+    close(y2, 1.0 + O.swish(x) @ W2.t(), what="swish linear accumulate")
+
+
+def test_ddpm_step_bit_exact_and_nan_flag():
+    g = torch.Generator().manual_seed(2)
+    n, T, w = 3 * 33 * 31, 50, 1.8
+    x, ec, eu, z = [torch.randn(n, generator=g) for _ in range(4)]
+    sched = O.sampler_schedule(1e-4, 0.028, T)
+    var = O.sampler_variance_table(sched)
+    c1, c2, sg = sched["coeff1"].float(), sched["coeff2"].float(), torch.sqrt(var.float())
+    lib, s = _capi.lib(), torch.cuda.current_stream().cuda_stream
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d = lambda t: t.to(DEV)
+    dx, dec, deu, dz, dc1, dc2, dsg = d(x), d(ec), d(eu), d(z), d(c1), d(c2), d(sg)
+    for step in (37, 0):
+        st = torch.tensor([step], dtype=torch.int32, device=DEV)
+        out = torch.empty(n, device=DEV)
+        _capi.check(lib.hdiff_ddpm_step(dx.data_ptr(), dec.data_ptr(), deu.data_ptr(), dz.data_ptr(), out.data_ptr(),
+                                        dc1.data_ptr(), dc2.data_ptr(), dsg.data_ptr(), st.data_ptr(), C.c_double(w),
+                                        C.c_uint64(0), flag.data_ptr(), n, s))
+        eps = (1. + w) * ec - w * eu                          # DiffusionCondition.py:78
+        mean = c1[step] * x - c2[step] * eps                  # :68-70
+        ref = mean + sg[step] * z if step > 0 else mean       # :91-95
+        assert torch.equal(out.cpu(), ref), f"ddpm_step not bit-exact at step {step}"
+    assert flag.item() == 0
+    dec[5] = float("nan")
+    st = torch.tensor([3], dtype=torch.int32, device=DEV)
+    _capi.check(lib.hdiff_ddpm_step(dx.data_ptr(), dec.data_ptr(), deu.data_ptr(), dz.data_ptr(), out.data_ptr(),
+                                    dc1.data_ptr(), dc2.data_ptr(), dsg.data_ptr(), st.data_ptr(), C.c_double(w),
+                                    C.c_uint64(0), flag.data_ptr(), n, s))
+    assert flag.item() == 1
+
+
+def test_q_sample_bit_exact_and_clip():
+    g = torch.Generator().manual_seed(4)
+    B, per = 4, 3 * 16 * 16
+    x0, nz = torch.rand(B, per, generator=g) * 2 - 1, torch.randn(B, per, generator=g)
+    t = torch.tensor([0, 7, 3, 5])
+    sched = O.trainer_schedule(1e-4, 0.028, 8)
+    ref = O.q_sample(sched, x0.view(B, 3, 16, 16), t, nz.view(B, 3, 16, 16)).view(B, per)
+    sa, sb = sched["sqrt_alphas_bar"].float().to(DEV), sched["sqrt_one_minus_alphas_bar"].float().to(DEV)
+    out = torch.empty(B, per, device=DEV)
+    lib, s = _capi.lib(), torch.cuda.current_stream().cuda_stream
+    d_x0, d_nz, d_t = x0.to(DEV), nz.to(DEV), t.to(DEV)
+    _capi.check(lib.hdiff_q_sample(d_x0.data_ptr(), d_nz.data_ptr(), d_t.data_ptr(), sa.data_ptr(),
+                                   sb.data_ptr(), out.data_ptr(), B, per, s))
+    assert torch.equal(out.cpu(), ref)
+    big = torch.randn(1000, generator=g) * 3
+    y = torch.empty(1000, device=DEV)
+    d_big = big.to(DEV)
+    _capi.check(lib.hdiff_clip(d_big.data_ptr(), y.data_ptr(), C.c_float(-1), C.c_float(1), 1000, s))
+    assert torch.equal(y.cpu(), torch.clip(big, -1, 1))
+
+
+def test_randn_moments_and_determinism():
+    n = 1 << 20
+    a, b, c = [torch.empty(n, device=DEV) for _ in range(3)]
+    lib, s = _capi.lib(), torch.cuda.current_stream().cuda_stream
+    _capi.check(lib.hdiff_randn(a.data_ptr(), n, C.c_uint64(42), C.c_uint64(0), s))
+    _capi.check(lib.hdiff_randn(b.data_ptr(), n, C.c_uint64(42), C.c_uint64(0), s))
+    _capi.check(lib.hdiff_randn(c.data_ptr(), n, C.c_uint64(42), C.c_uint64(1), s))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3
+    assert abs((a ** 4).mean().item() - 3) < 0.05
+    assert abs((a * c).mean().item()) < 5e-3
+    assert torch.isfinite(a).all()
