@@ -1,0 +1,105 @@
+"""One process per GPU over torch.distributed (backend "nccl" is RCCL on ROCm; "gloo" for the CPU rehearsal in tests).
+
+The reference's hot path has no distributed code (TrainCondition.py:21 uses a single device); its other tree launches
+DDP with one process per GPU (utils/rotinas.py:572-577, 619).  The hot path shards like this:
+
+* sampling: images are independent -- each rank takes a contiguous slice of the batch with its own seed and there is NO
+  data-path collective (only the bench's barrier / max-over-ranks timing);
+* training: replicated weights, per-rank mini-batch, ONE exchange per optimizer step: the mean of the 47.8 M fp32
+  gradients (190.8 MB).  On the MI355X node xGMI is a full mesh of point-to-point links, so the flat gradient buffer is
+  reduced with reduce-scatter + all-gather (every link busy at once) rather than a ring all-reduce of small buckets.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """Initialise the default process group from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; returns (rank, local, world)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
+    return rank, local, world
+
+
+def shard_range(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced slice [lo, hi) of n independent units for this rank (first n % world ranks get one extra)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def rank_seed(base_seed: int, rank: int) -> int:
+    """Per-rank RNG seed for independent sampling trajectories."""
+    return (int(base_seed) * 1000003 + 7919 * int(rank)) & 0x7FFFFFFFFFFFFFFF
+
+
+def broadcast_parameters_(params: Iterable[torch.Tensor], src: int = 0) -> None:
+    """Make every rank start from rank `src`'s weights (what DDP does at construction, rotinas.py:619)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    for p in params:
+        dist.broadcast(p.data, src=src)
+
+
+def allreduce_mean_grads_(params: Sequence[torch.nn.Parameter]) -> int:
+    """Average the gradients of `params` over all ranks in ONE flat fp32 buffer; returns the bytes exchanged per rank.
+
+    nccl/RCCL: reduce-scatter + all-gather on the flat buffer (full-mesh xGMI: all 7 links busy); gloo: all_reduce.
+    Parameters without a gradient contribute zeros (the reference's optimizer skips them identically on every rank).
+    """
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    ps = [p for p in params if p.requires_grad]
+    if not ps:
+        return 0
+    dev = ps[0].device
+    n = sum(p.numel() for p in ps)
+    padded = (n + world - 1) // world * world
+    flat = torch.zeros(padded, dtype=torch.float32, device=dev)
+    off = 0
+    for p in ps:
+        if p.grad is not None:
+            flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        off += p.numel()
+    if dist.get_backend() == "nccl":
+        shard = torch.empty(padded // world, dtype=torch.float32, device=dev)
+        dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+        shard.div_(world)
+        dist.all_gather_into_tensor(flat, shard)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+    off = 0
+    for p in ps:
+        g = flat[off:off + p.numel()].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()
+    return padded * 4
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,121 @@
+"""CPU-only checks: the C-ABI library loads and exports everything include/hdiff.h declares, the host-side classes keep
+the reference's state_dict / buffers, and the product path refuses to run without an MI355X (no fallback)."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import hdiff_amd
+from hdiff_amd import _capi, engine as E
+from hdiff_amd.DiffusionFreeGuidence import DiffusionCondition as DC
+from hdiff_amd.DiffusionFreeGuidence import ModelCondition as MC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "hdiff.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hdiff_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = hdiff_amd.lib()
+    assert lib.hdiff_abi_version() == 1
+    syms = header_symbols()
+    assert len(syms) >= 25
+    out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (hdiff_[a-z0-9_]+)", out))
+    assert set(syms) <= exported, sorted(set(syms) - exported)
+    assert set(_capi.EXPORTED_SYMBOLS) == set(syms), set(_capi.EXPORTED_SYMBOLS) ^ set(syms)
+    assert lib.hdiff_device_count() >= 0
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate shapes on the host before any launch (no compute call is made here)."""
+    lib = hdiff_amd.lib()
+    assert lib.hdiff_mha_flash_fwd(1, 1, 1, 40, 8, 16, None) == -1            # head dim 5 unsupported
+    assert b"head dim" in lib.hdiff_last_error()
+    assert lib.hdiff_gn_stats(1, None, 48, 0, 1, 16, 32, 1, 1, None) == -1      # 48 channels / 32 groups
+    d = _capi.ConvDesc()
+    assert lib.hdiff_conv2d_fwd(d, None) == -1
+
+
+def test_product_path_refuses_cpu_tensors():
+    m = MC.UNet(T=8, num_labels=3, ch=32, ch_mult=[1, 2], num_res_blocks=1, dropout=0.0).eval()
+    x, t, lab = torch.zeros(1, 3, 16, 16), torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.long)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x, t, lab)
+    samp = DC.GaussianDiffusionSampler(m, 1e-4, 0.028, 8, w=1.8)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        samp(x, lab)
+    tr = DC.GaussianDiffusionTrainer(m, 1e-4, 0.028, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tr(x, lab)
+    with pytest.raises(RuntimeError):
+        E.Plan("cpu")
+
+
+def test_state_dict_layout_and_seeded_init_match_reference():
+    with open(os.path.join(GOLDEN, "state_dict_default.json")) as fh:
+        ref = json.load(fh)
+    d = np.load(os.path.join(GOLDEN, "unet_default64.npz"))
+    cfg = json.loads(bytes(d["cfg_json"]).decode())
+    torch.manual_seed(int(d["seed"][0]))
+    m = MC.UNet(**cfg)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == ref["entries"]
+    assert sum(p.numel() for p in m.parameters()) == ref["n_params"]
+    sd = m.state_dict()
+    names = sorted(sd.keys())
+    assert names == list(d["weight_names"])
+    table = "time_embedding.timembedding.0.weight"
+    for n, want in zip(names, d["weight_checksums"]):
+        bits = sd[n].float().contiguous().reshape(-1).view(torch.int32).to(torch.int64)
+        got = [int(bits.sum().item()), bits.numel(), int(bits[0].item()), int(bits[-1].item())]
+        if n != table:
+            assert got == list(want), n
+    assert (sd[table][417] - torch.from_numpy(d["temb_row_417"])).abs().max().item() < 1e-4
+    assert torch.all(sd["cond_embedding.condEmbedding.0.weight"][0] == 0)       # padding_idx row
+
+
+def test_small_state_dict_loads_strict_and_buffers_bit_exact():
+    u = np.load(os.path.join(GOLDEN, "unet_small.npz"))
+    cfg = json.loads(bytes(u["cfg_json"]).decode())
+    m = MC.UNet(**cfg)
+    sd = {k[3:]: torch.from_numpy(u[k]) for k in u.files if k.startswith("sd/")}
+    m.load_state_dict(sd, strict=True)
+    s = np.load(os.path.join(GOLDEN, "schedules.npz"))
+    for i in range(3):
+        b1, bT, Tn = s[f"cfg{i}"]
+        tr = DC.GaussianDiffusionTrainer(m, float(b1), float(bT), int(Tn))
+        sa = DC.GaussianDiffusionSampler(m, float(b1), float(bT), int(Tn), w=1.8)
+        assert [n for n, _ in tr.named_buffers(recurse=False)] == ["betas", "sqrt_alphas_bar", "sqrt_one_minus_alphas_bar"]
+        assert [n for n, _ in sa.named_buffers(recurse=False)] == ["betas", "coeff1", "coeff2", "posterior_var"]
+        for n in ("betas", "sqrt_alphas_bar", "sqrt_one_minus_alphas_bar"):
+            assert getattr(tr, n).dtype == torch.float64
+            assert np.array_equal(getattr(tr, n).numpy(), s[f"cfg{i}/trainer/{n}"])
+        for n in ("betas", "coeff1", "coeff2", "posterior_var"):
+            assert np.array_equal(getattr(sa, n).numpy(), s[f"cfg{i}/sampler/{n}"])
+        ex = DC.extract(sa.coeff2, torch.from_numpy(s[f"cfg{i}/extract_t"]), (4, 3, 8, 8))
+        assert np.array_equal(ex.numpy(), s[f"cfg{i}/extract_coeff2"])
+        assert sa.model is m and sa.T == int(Tn) and sa.w == 1.8
+
+
+def test_transposed_conv_phases_cover_every_tap_once():
+    seen = set()
+    for py in (0, 1):
+        for px in (0, 1):
+            t = E.tconv_phase_taps(py, px)
+            assert len(t.dy) == (3 if py == 0 else 2) * (3 if px == 0 else 2)
+            for dy, dx, ky, kx in zip(t.dy, t.dx, t.ky, t.kx):
+                assert (2 * 0 + py) == 2 * dy - 2 + ky and (2 * 0 + px) == 2 * dx - 2 + kx    # oy = 2*iy - 2 + ky at y = 0
+                assert (ky, kx) not in seen
+                seen.add((ky, kx))
+    assert len(seen) == 25
+    t5 = E.conv_taps(5, 2)
+    assert (min(t5.dy), max(t5.dy), len(t5.dy)) == (-2, 2, 25)
