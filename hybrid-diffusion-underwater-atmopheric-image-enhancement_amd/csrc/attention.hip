@@ -15,11 +15,15 @@
 // {r, 4+r, 8+r, 12+r}.  No cross-lane movement between the two products; softmax needs two lane exchanges per 64 keys.
 // Online softmax: running max m and partial row sum l per query (lane-local, the four lane groups hold partial sums).
 //
-// Schedule: a wave owns NQ query tiles of 16.  Within a key tile the three stages of consecutive query tiles are
-// software-pipelined in ONE instruction stream,
-//        QK^T(q+1)   ||   softmax(q)   ||   P.V(q-1)
-// so the matrix pipe (two MFMA streams, alternated so dependent accumulations are never back to back) always has the
-// exp/max/sum VALU work of the middle stage issuing in its shadow (sched_group_barrier pins "1 MFMA : few VALU").
+// Cost model (measured on MI355X, tools/mfma_valu.hip): an fp32 MFMA and an ordinary VALU instruction do NOT overlap on
+// a SIMD -- the fp32 MFMA runs at the vector FMA rate and every VALU instruction (about 5 cycles, v_exp_f32 about 11) is
+// issue time taken away from the MFMA stream, even from a second wave.  The kernel therefore minimises VALU work per score:
+//   * lazy running max: m only moves when some score exceeds it by more than 2^64 (detected from the row sum itself, so
+//     the common path has no max at all): p = exp2(s - m) directly; fp32 keeps full relative precision at any scale,
+//   * packed fp32 math (v_pk_add_f32) for the subtract and the row sums: two scores per instruction,
+//   * MFMA accumulators kept in VGPRs (-amdgpu-mfma-vgpr-form): no v_accvgpr copies between the products and softmax.
+// A wave owns NQ query tiles of 16 and walks them one at a time per key tile; P.V(q) and QK^T(q+1) MFMAs are alternated
+// so that dependent accumulations are never issued back to back.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -33,11 +37,11 @@ namespace {
 constexpr int KT = 64;          // keys per tile
 constexpr int KROW = KT + 4;    // LDS row stride (floats), 16-byte aligned rows
 constexpr int ATT_THREADS = 256;
+constexpr float RESCALE_LIMIT = 1.8446744e19f;   // 2^64: a row sum at or above it (or inf) triggers the max update
 
-#define SGB_MFMA 0x008
-#define SGB_VALU_TRANS 0x402   // VALU | TRANS (v_exp_f32 is a TRANS instruction)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int D, int NQ, int VARIANT>
+template <int D, int NQ>
 __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                     int C, int L, float qscale) {
   constexpr int KS = D / 4;                 // k-steps of the QK^T product
@@ -114,17 +118,19 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float*
     }
   };
 
+  f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  asm volatile("" : "+v"(zero4));     // opaque: keep ONE live zero tuple instead of re-materialising zeros per MFMA chain
   f32x4 O[MT][NQ];
   float m_run[NQ], l_run[NQ];
 #pragma unroll
   for (int qt = 0; qt < NQ; ++qt) {
-    m_run[qt] = -1e30f;
+    m_run[qt] = -1e30f;       // finite: the first tile always takes the max-update path (s - m overflows exp2)
     l_run[qt] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) O[mt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // One key tile.  MASK: the tile holds keys >= L (last tile of a ragged sequence).
+  // One key tile.  MASK: the tile may hold keys >= L (ragged / unaligned sequences).
   auto do_tile = [&](auto mask_tag, int t, int buf) {
     constexpr bool MASK = decltype(mask_tag)::value;
     // K and V fragments of the whole tile, shared by all NQ query tiles of this wave
@@ -140,96 +146,82 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float*
         vf[ks][mt][0] = v4.x; vf[ks][mt][1] = v4.y; vf[ks][mt][2] = v4.z; vf[ks][mt][3] = v4.w;
       }
     }
-    f32x4 S[NQ][4];
+    f32x4 S[2][4];     // scores of the current and the next query tile
+    f32x4 P[4];
+    const f32x4 ZERO4 = zero4;
 
     auto qk_mfma = [&](int qt, int i) {       // i-th MFMA of QK^T(qt): k-step s = i / 4, key subtile ks = i % 4
       const int s = i >> 2, ks = i & 3;
-      if (s == 0) S[qt][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
-      S[qt][ks] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks][s], qf[qt][s], S[qt][ks], 0, 0, 0);
+      // the first k-step reads the shared zero tuple as C: no per-chain zeroing of the accumulator registers
+      S[qt & 1][ks] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks][s], qf[qt][s], s == 0 ? ZERO4 : S[qt & 1][ks], 0, 0, 0);
     };
     auto pv_mfma = [&](int qt, int i) {       // i-th MFMA of P.V(qt): mt = i % MT, then key subtile / register
       const int mt = i % MT, j = i / MT, ks = j >> 2, r = j & 3;
-      O[mt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[ks][mt][r], S[qt][ks][r], O[mt][qt], 0, 0, 0);
+      O[mt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[ks][mt][r], P[ks][r], O[mt][qt], 0, 0, 0);
     };
     auto softmax = [&](int qt) {
+      f32x4(&Sq)[4] = S[qt & 1];
       if (MASK) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (t * KT + ks * 16 + 4 * g + r >= L) S[qt][ks][r] = -1e30f;
+            if (t * KT + ks * 16 + 4 * g + r >= L) Sq[ks][r] = -__builtin_inff();
       }
-      float tm = fmaxf(fmaxf(S[qt][0][0], S[qt][0][1]), S[qt][0][2]);
-      tm = fmaxf(fmaxf(tm, S[qt][0][3]), S[qt][1][0]);
-      tm = fmaxf(fmaxf(tm, S[qt][1][1]), S[qt][1][2]);
-      tm = fmaxf(fmaxf(tm, S[qt][1][3]), S[qt][2][0]);
-      tm = fmaxf(fmaxf(tm, S[qt][2][1]), S[qt][2][2]);
-      tm = fmaxf(fmaxf(tm, S[qt][2][3]), S[qt][3][0]);
-      tm = fmaxf(fmaxf(tm, S[qt][3][1]), S[qt][3][2]);
-      tm = fmaxf(tm, S[qt][3][3]);
-      tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
-      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-      const float m_new = fmaxf(m_run[qt], tm);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-      m_run[qt] = m_new;
-      float ls0 = 0.f, ls1 = 0.f;
+      // common path: no max, two scores per packed instruction
+      const f32x2 nm2 = {-m_run[qt], -m_run[qt]};     // added, not subtracted: a v2f32 fadd selects v_pk_add_f32
+      f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x2 a = __builtin_shufflevector(Sq[ks], Sq[ks], 0, 1) + nm2;
+        const f32x2 c = __builtin_shufflevector(Sq[ks], Sq[ks], 2, 3) + nm2;
+        const f32x2 pa = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+        const f32x2 pc = {__builtin_amdgcn_exp2f(c.x), __builtin_amdgcn_exp2f(c.y)};
+        sum2 += pa;
+        sum2 += pc;
+        P[ks] = f32x4{pa.x, pa.y, pc.x, pc.y};
+      }
+      float ls = sum2.x + sum2.y;
+      if (__any(!(ls < RESCALE_LIMIT))) {
+        // rare path (always the first tile): move the running max, rescale what was accumulated at the old one
+        float tm = fmaxf(fmaxf(Sq[0][0], Sq[0][1]), fmaxf(Sq[0][2], Sq[0][3]));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(S[qt][ks][r] - m_new);
-          S[qt][ks][r] = pv;
-          if (r & 1) ls1 += pv; else ls0 += pv;
-        }
-      l_run[qt] = l_run[qt] * alpha + (ls0 + ls1);
+        for (int ks = 1; ks < 4; ++ks) tm = fmaxf(tm, fmaxf(fmaxf(Sq[ks][0], Sq[ks][1]), fmaxf(Sq[ks][2], Sq[ks][3])));
+        tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        const float m_new = fmaxf(m_run[qt], tm);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+        m_run[qt] = m_new;
+        ls = 0.f;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) O[mt][qt] *= alpha;
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(Sq[ks][r] - m_new);
+            P[ks][r] = pv;
+            ls += pv;
+          }
+        l_run[qt] = l_run[qt] * alpha + ls;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) O[mt][qt] *= alpha;
+      } else {
+        l_run[qt] += ls;
+      }
     };
 
-    if (VARIANT == 0 || VARIANT >= 3) {
-      // plain order: all QK^T, all softmax, all P.V (hardware overlap between co-resident waves only)
-#pragma unroll
-      for (int qt = 0; qt < NQ; ++qt)
-#pragma unroll
-        for (int i = 0; i < N_QK; ++i) qk_mfma(qt, i);
-#pragma unroll
-      for (int qt = 0; qt < NQ; ++qt)
-        if (VARIANT != 3) softmax(qt);      // 3 = timing-only ablation (wrong results): no softmax
-#pragma unroll
-      for (int i = 0; i < N_PV; ++i)
-#pragma unroll
-        for (int qt = 0; qt < NQ; ++qt) pv_mfma(qt, i);
-      return;
-    }
-    // ---- software pipeline over the wave's query tiles
 #pragma unroll
     for (int i = 0; i < N_QK; ++i) qk_mfma(0, i);
 #pragma unroll
     for (int qt = 0; qt < NQ; ++qt) {
-      // MFMA streams of this step, alternated: P.V(qt-1) and QK^T(qt+1)
+      softmax(qt);
+      // P.V(qt) alternated with QK^T(qt+1): consecutive MFMAs never accumulate into the same registers
       constexpr int NMAX = (N_QK > N_PV) ? N_QK : N_PV;
 #pragma unroll
       for (int i = 0; i < NMAX; ++i) {
-        if (qt > 0 && i < N_PV) pv_mfma(qt - 1, i);
+        if (i < N_PV) pv_mfma(qt, i);
         if (qt + 1 < NQ && i < N_QK) qk_mfma(qt + 1, i);
       }
-      softmax(qt);
-      // pin the interleave: one MFMA, then a few VALU/TRANS of softmax(qt)
-      const int n_mfma = ((qt > 0) ? N_PV : 0) + ((qt + 1 < NQ) ? N_QK : 0);
-      if (VARIANT == 2 && n_mfma > 0) {
-        const int per = (80 + n_mfma - 1) / n_mfma;
-#pragma unroll
-        for (int i = 0; i < n_mfma; ++i) {
-          __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);
-          if (per <= 2) __builtin_amdgcn_sched_group_barrier(SGB_VALU_TRANS, 2, 0);
-          else if (per == 3) __builtin_amdgcn_sched_group_barrier(SGB_VALU_TRANS, 3, 0);
-          else if (per == 4) __builtin_amdgcn_sched_group_barrier(SGB_VALU_TRANS, 4, 0);
-          else __builtin_amdgcn_sched_group_barrier(SGB_VALU_TRANS, 5, 0);
-        }
-      }
     }
-#pragma unroll
-    for (int i = 0; i < N_PV; ++i) pv_mfma(NQ - 1, i);
   };
 
   stage_load(0);
@@ -240,13 +232,11 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float*
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
     const int tn = (t + 1 < ntiles) ? t + 1 : t;   // the last iteration re-stages its own tile (branch-free; unused)
-    if (VARIANT != 4) stage_load(tn);               // 4 = timing-only ablation (wrong results): no staging, no barrier
-    if (t < nfull) do_tile(std::false_type{}, t, VARIANT == 4 ? 0 : buf);
+    stage_load(tn);
+    if (t < nfull) do_tile(std::false_type{}, t, buf);
     else do_tile(std::true_type{}, t, buf);
-    if (VARIANT != 4) {
-      stage_store(buf ^ 1);
-      __syncthreads();
-    }
+    stage_store(buf ^ 1);
+    __syncthreads();
   }
 
   // ---- normalise and store: out[b][head*D + d][q]
@@ -270,36 +260,30 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float*
   }
 }
 
-int att_variant() {
+int att_nq_override() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("HDIFF_ATT_VARIANT");
+    const char* e = getenv("HDIFF_ATT_NQ");   // dev knob: force the query tiles per wave (1, 4 or 8)
     v = e ? atoi(e) : 0;
   }
   return v;
 }
 
-template <int D, int NQ, int VARIANT>
+template <int D, int NQ>
 void launch_v(const float* qkv, float* o, int B, int C, int heads, int L, float qscale, hipStream_t stream) {
   dim3 grid(cdiv(L, 64 * NQ), heads, B);
-  hipLaunchKernelGGL((mha_flash_fwd_kernel<D, NQ, VARIANT>), grid, dim3(ATT_THREADS), 0, stream, qkv, o, C, L, qscale);
+  hipLaunchKernelGGL((mha_flash_fwd_kernel<D, NQ>), grid, dim3(ATT_THREADS), 0, stream, qkv, o, C, L, qscale);
 }
 
 template <int D>
 int launch_d(const float* qkv, float* o, int B, int C, int heads, int L, hipStream_t stream) {
   const float qscale = 1.4426950408889634f / sqrtf((float)D);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  if (L >= 512) {
-    switch (att_variant()) {
-      case 1: launch_v<D, 4, 1>(qkv, o, B, C, heads, L, qscale, stream); break;
-      case 2: launch_v<D, 4, 2>(qkv, o, B, C, heads, L, qscale, stream); break;
-      case 3: launch_v<D, 4, 3>(qkv, o, B, C, heads, L, qscale, stream); break;
-      case 4: launch_v<D, 4, 4>(qkv, o, B, C, heads, L, qscale, stream); break;
-      default: launch_v<D, 4, 0>(qkv, o, B, C, heads, L, qscale, stream); break;
-    }
-  } else {
-    launch_v<D, 1, 0>(qkv, o, B, C, heads, L, qscale, stream);
-  }
+  int nq = (L >= 512) ? 4 : 1;   // 4 query tiles per wave: 3 waves per SIMD at d_head 16, 2 at d_head 32 (8 tiles measured no faster)
+  if (att_nq_override() > 0) nq = att_nq_override();
+  if (nq >= 8) launch_v<D, 8>(qkv, o, B, C, heads, L, qscale, stream);
+  else if (nq >= 4) launch_v<D, 4>(qkv, o, B, C, heads, L, qscale, stream);
+  else launch_v<D, 1>(qkv, o, B, C, heads, L, qscale, stream);
   HDIFF_CHECK_LAUNCH("mha_flash_fwd_kernel");
   return HDIFF_OK;
 }

@@ -8,6 +8,8 @@
 //   * the NCHW input patch (tile + halo) of CK channels into LDS once -- every tap reads it at a shifted address, and
 //     GroupNorm-affine + Swish (the reference's block1/block2 prologue) is applied while staging,
 //   * the packed weight slab [ntaps][CK][64] with 16-byte loads.
+// Global loads of chunk c+1 are issued before the MFMAs of chunk c and stay in flight under them; LDS operands are
+// fetched one (tap, k-pair) step ahead of the MFMAs that consume them.
 // Each wave owns 64 channels x (32*WN) pixels: 2 x WN accumulators of 32x32 (16 VGPRs each).
 // fp32 MFMA is exact fp32 (a k-ordered fma chain), so results differ from the reference only by summation order.
 #include "common.h"
@@ -32,16 +34,26 @@ struct ConvK {
   const float* residual;
   float* out;
   int OH, OW, VH, VW, in_stride, out_sy, out_oy, out_sx, out_ox;
-  int ntaps, dy_min, dx_min, PH, PW, PWp, PLANE, XFLOATS;
+  int ntaps, dy_min, dx_min, PH, PW, PWp, PLANE, XFLOATS, WFLOATS;
   int tw_log2, TH, tiles_x;
+  int nx, nw;                      // staging slots in use per thread (activation floats, weight float4s)
   int tap_off[HDIFF_MAX_TAPS];
 };
 
-template <int WN, int CK>
+// Swish with the hardware reciprocal (1 ulp) instead of an IEEE division: the prologue runs once per staged element
+// and, on gfx950, every VALU instruction is issue time taken from the fp32 MFMA stream.
+__device__ __forceinline__ float swish_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// Pipeline per CK-channel chunk (one LDS buffer, two barriers):
+//   [registers of chunk c hold the prefetched patch + weight slab]
+//   transform (GroupNorm affine + Swish) and store them to LDS | barrier | issue the global loads of chunk c+1 (they stay
+//   in flight under the MFMAs) | taps x k-pairs of MFMAs, operands prefetched from LDS one step ahead | barrier
+template <int WN, int CK, int NXS, int NWS>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sX = smem;               // [CK][PLANE]
-  float* sW = smem + p.XFLOATS;   // [ntaps][CK][BM]
+  float* sX = smem;                       // [CK][PLANE]
+  float* sW = smem + p.XFLOATS;           // [ntaps][CK][BM]
+  float* sG = sW + p.WFLOATS;             // [2][Cin]: GroupNorm scale | shift of this sample
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -53,6 +65,40 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   const int vy0 = tile_y * p.TH, vx0 = tile_x << p.tw_log2;
   const int iy0 = vy0 * p.in_stride + p.dy_min, ix0 = vx0 * p.in_stride + p.dx_min;
   const bool has_gn = p.gn_scale != nullptr;
+  const size_t HW = (size_t)p.H * p.W;
+
+  // ---- per-thread staging slots, fixed for the whole kernel (the patch geometry is the same for every chunk)
+  int x_soff[NXS];     // ci*H*W + iy*W + ix inside the chunk's first plane, or -1 when the position is zero padding
+  int x_meta[NXS];     // LDS float offset | ci << 24
+  {
+    const int plane_elems = p.PH * p.PW;
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      const int e = tid + i * NTHREADS;
+      const int ci = e / plane_elems;
+      const int rem = e - ci * plane_elems;
+      const int py = rem / p.PW, px = rem - py * p.PW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool in_slot = (i < p.nx) && (ci < CK);
+      const bool in_img = in_slot && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      x_soff[i] = in_img ? (int)(ci * HW) + iy * p.W + ix : -1;
+      x_meta[i] = in_slot ? ((ci * p.PLANE + py * p.PWp + px) | (ci << 24)) : -1;
+    }
+  }
+  int w_goff[NWS];     // float offset of the slot's 16-byte vector inside the chunk's weight slab, or -1
+#pragma unroll
+  for (int i = 0; i < NWS; ++i) {
+    const int idx = tid + i * NTHREADS;
+    const int row = idx >> 4, seg = idx & 15;
+    const int tap = row / CK, ci = row - tap * CK;
+    w_goff[i] = (i < p.nw && tap < p.ntaps) ? (tap * p.CinPad + ci) * p.CoutPad + seg * 4 : -1;
+  }
+  if (has_gn) {
+    for (int i = tid; i < 2 * p.Cin; i += NTHREADS)
+      sG[i] = (i < p.Cin) ? p.gn_scale[b * p.Cin + i] : p.gn_shift[b * p.Cin + (i - p.Cin)];
+  }
+  // tap offsets live across the lanes of one register: read back with v_readlane (no memory access in the MFMA loop)
+  const int tapv = (lane < p.ntaps) ? p.tap_off[lane] : 0;
 
   int pixoff[WN];
 #pragma unroll
@@ -70,75 +116,79 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   const bool two_m = (p.Cout - co0) > 32;
-  const size_t HW = (size_t)p.H * p.W;
 
+  float xr[NXS];
+  float4 wr[NWS];
+  auto issue_loads = [&](int c0) {
+    // a chunk never straddles the concat seam (C0 % CK == 0 is checked on the host)
+    const float* xbase = (c0 < p.C0) ? p.x0 + ((size_t)b * p.C0 + c0) * HW : p.x1 + ((size_t)b * p.C1 + (c0 - p.C0)) * HW;
+    const int c_left = p.Cin - c0;     // channels of this chunk that exist
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      const bool ok = x_soff[i] >= 0 && (x_meta[i] >> 24) < c_left;
+      xr[i] = ok ? xbase[x_soff[i]] : 0.f;
+    }
+    const float* wbase = p.wp + (size_t)c0 * p.CoutPad + co0;
+#pragma unroll
+    for (int i = 0; i < NWS; ++i)
+      wr[i] = (w_goff[i] >= 0) ? *reinterpret_cast<const float4*>(wbase + w_goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_staged = [&](int c0) {
+    const int c_left = p.Cin - c0;
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      if (x_meta[i] >= 0) {
+        float v = xr[i];
+        const int ci = x_meta[i] >> 24;
+        if (has_gn && x_soff[i] >= 0 && ci < c_left) v = swish_fast(fmaf(v, sG[c0 + ci], sG[p.Cin + c0 + ci]));
+        sX[x_meta[i] & 0xFFFFFF] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NWS; ++i)
+      if (w_goff[i] >= 0) reinterpret_cast<float4*>(sW)[tid + i * NTHREADS] = wr[i];
+  };
+
+  constexpr int KH2 = CK / 2;
+  const int nsteps = p.ntaps * KH2;
+  const float* sXh = sX + h * p.PLANE;
+  const float* sWh = sW + h * BM + l31;
+  const int plane2 = 2 * p.PLANE;
+
+  issue_loads(0);
+  __syncthreads();     // sG visible
   for (int c0 = 0; c0 < p.CinPad; c0 += CK) {
+    store_staged(c0);
     __syncthreads();
-    // ---- stage the activation patch: one half-wave per (channel, patch row)
-    {
-      const int l32 = tid & 31;
-      int ci = 0, py = tid >> 5;
-      while (py >= p.PH) { py -= p.PH; ++ci; }
-      while (ci < CK) {
-        const int c = c0 + ci;
-        const int iy = iy0 + py;
-        const bool row_ok = (c < p.Cin) && (iy >= 0) && (iy < p.H);
-        const float* src = nullptr;
-        float sc = 1.f, sh = 0.f;
-        if (row_ok) {
-          src = (c < p.C0) ? p.x0 + ((size_t)b * p.C0 + c) * HW : p.x1 + ((size_t)b * p.C1 + (c - p.C0)) * HW;
-          src += (size_t)iy * p.W;
-          if (has_gn) {
-            sc = p.gn_scale[b * p.Cin + c];
-            sh = p.gn_shift[b * p.Cin + c];
-          }
-        }
-        float* dst = sX + ci * p.PLANE + py * p.PWp;
-        for (int px = l32; px < p.PW; px += 32) {
-          const int ix = ix0 + px;
-          float v = 0.f;
-          if (row_ok && ix >= 0 && ix < p.W) {
-            v = src[ix];
-            if (has_gn) v = swishf(fmaf(v, sc, sh));
-          }
-          dst[px] = v;
-        }
-        py += 8;
-        while (py >= p.PH) { py -= p.PH; ++ci; }
+    if (c0 + CK < p.CinPad) issue_loads(c0 + CK);
+
+    // ---- MFMA over (tap, k-pair) steps.  Lane half h supplies k = 2*k2 + h for both operands.
+    float a0A, a1A, a0B, a1B, bA[WN], bB[WN];
+    auto frag = [&](int step, float& a0, float& a1, float (&bf)[WN]) {
+      const int tap = step / KH2, k2 = step - tap * KH2;
+      const float* xb = sXh + __builtin_amdgcn_readlane(tapv, tap) + k2 * plane2;
+      const float* wb = sWh + (tap * CK + 2 * k2) * BM;
+      a0 = wb[0];
+      a1 = wb[32];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) bf[nt] = xb[pixoff[nt]];
+    };
+    auto mma = [&](float a0, float a1, const float (&bf)[WN]) {
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[nt], acc[0][nt], 0, 0, 0);
+      if (two_m) {
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[nt], acc[1][nt], 0, 0, 0);
       }
-    }
-    // ---- stage the weight slab [ntaps][CK][BM] (rows of 64 floats, 16-byte accesses)
-    {
-      const int nvec = p.ntaps * CK * (BM / 4);
-      for (int idx = tid; idx < nvec; idx += NTHREADS) {
-        const int row = idx >> 4, seg = idx & 15;
-        const int tap = row / CK, ci = row - tap * CK;
-        const float4* g =
-            reinterpret_cast<const float4*>(p.wp + ((size_t)tap * p.CinPad + c0 + ci) * p.CoutPad + co0) + seg;
-        reinterpret_cast<float4*>(sW)[idx] = *g;
-      }
+    };
+    frag(0, a0A, a1A, bA);
+    for (int step = 0; step < nsteps; step += 2) {        // nsteps is even (CK/2 is 2 or 4)
+      frag(step + 1, a0B, a1B, bB);
+      mma(a0A, a1A, bA);
+      frag(step + 2 < nsteps ? step + 2 : step, a0A, a1A, bA);
+      mma(a0B, a1B, bB);
     }
     __syncthreads();
-    // ---- MFMA over taps x k-pairs.  Lane half h supplies k = 2*k2 + h for both operands.
-    for (int tap = 0; tap < p.ntaps; ++tap) {
-      const float* xb = sX + p.tap_off[tap] + h * p.PLANE;
-      const float* wb = sW + (tap * CK + h) * BM + l31;
-#pragma unroll
-      for (int k2 = 0; k2 < CK / 2; ++k2) {
-        const float a0 = wb[(2 * k2) * BM];
-        const float a1 = wb[(2 * k2) * BM + 32];
-        float bf[WN];
-#pragma unroll
-        for (int nt = 0; nt < WN; ++nt) bf[nt] = xb[(2 * k2) * p.PLANE + pixoff[nt]];
-#pragma unroll
-        for (int nt = 0; nt < WN; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[nt], acc[0][nt], 0, 0, 0);
-        if (two_m) {
-#pragma unroll
-          for (int nt = 0; nt < WN; ++nt)
-            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[nt], acc[1][nt], 0, 0, 0);
-        }
-      }
-    }
   }
 
   // ---- epilogue: + bias + per-sample channel vector + residual, NCHW store (32 consecutive pixels per register row)
@@ -199,11 +249,11 @@ int ceil_log2(int v) {
   return l;
 }
 
-template <int WN, int CK>
+template <int WN, int CK, int NXS, int NWS>
 int launch(const ConvK& k, int B, size_t lds_bytes, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WN, CK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WN, CK, NXS, NWS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -212,7 +262,7 @@ int launch(const ConvK& k, int B, size_t lds_bytes, hipStream_t stream) {
   const int tiles_y = cdiv(k.VH, BN / TW);
   dim3 grid(k.tiles_x * tiles_y, cdiv(k.Cout, BM), B);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  hipLaunchKernelGGL((conv_igemm_kernel<WN, CK>), grid, dim3(NTHREADS), lds_bytes, stream, k);
+  hipLaunchKernelGGL((conv_igemm_kernel<WN, CK, NXS, NWS>), grid, dim3(NTHREADS), lds_bytes, stream, k);
   HDIFF_CHECK_LAUNCH("conv_igemm_kernel");
   return HDIFF_OK;
 }
@@ -285,19 +335,29 @@ extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream)
   k.PLANE = k.PH * k.PWp;
   for (int t = 0; t < d->ntaps; ++t) k.tap_off[t] = (d->tap_dy[t] - dy_min) * k.PWp + (d->tap_dx[t] - dx_min);
 
-  int CK = 8;
+  // configuration A: CK = 8 channels per chunk, <= 12 activation slots and <= 5 weight vectors per thread
+  // configuration B: CK = 4, <= 20 / <= 7 (5x5 stride-2 patches, very narrow images)
+  const int Cin = d->C0 + d->C1;
+  auto slots_x = [&](int ck) { return cdiv(ck * k.PH * k.PW, NTHREADS); };
+  auto slots_w = [&](int ck) { return cdiv(d->ntaps * ck * (BM / 4), NTHREADS); };
   auto lds_for = [&](int ck) {
     const int xfl = (ck * k.PLANE + 3) & ~3;
-    return (size_t)(xfl + d->ntaps * ck * BM) * sizeof(float);
+    return (size_t)(xfl + d->ntaps * ck * BM + 2 * Cin) * sizeof(float);
   };
-  if (lds_for(8) > 48 * 1024) CK = 4;
+  int CK = 0;
+  if (slots_x(8) <= 12 && slots_w(8) <= 5 && lds_for(8) <= 64 * 1024 && (d->C1 == 0 || d->C0 % 8 == 0)) CK = 8;
+  else if (slots_x(4) <= 20 && slots_w(4) <= 7 && lds_for(4) <= 96 * 1024 && (d->C1 == 0 || d->C0 % 4 == 0)) CK = 4;
+  HDIFF_CHECK_ARG(CK != 0, "conv2d_fwd: no kernel configuration fits (taps %d, patch %dx%d, C0 %d)", d->ntaps, k.PH, k.PW,
+                  d->C0);
   const size_t lds = lds_for(CK);
-  HDIFF_CHECK_ARG(lds <= 160 * 1024, "conv2d_fwd: tile needs %zu bytes of LDS", lds);
   k.XFLOATS = (CK * k.PLANE + 3) & ~3;
+  k.WFLOATS = d->ntaps * CK * BM;
+  k.nx = slots_x(CK);
+  k.nw = slots_w(CK);
 
   hipStream_t s = (hipStream_t)stream;
-  if (WN == 2 && CK == 8) return launch<2, 8>(k, d->B, lds, s);
-  if (WN == 2 && CK == 4) return launch<2, 4>(k, d->B, lds, s);
-  if (WN == 1 && CK == 8) return launch<1, 8>(k, d->B, lds, s);
-  return launch<1, 4>(k, d->B, lds, s);
+  if (WN == 2 && CK == 8) return launch<2, 8, 12, 5>(k, d->B, lds, s);
+  if (WN == 2 && CK == 4) return launch<2, 4, 20, 7>(k, d->B, lds, s);
+  if (WN == 1 && CK == 8) return launch<1, 8, 12, 5>(k, d->B, lds, s);
+  return launch<1, 4, 20, 7>(k, d->B, lds, s);
 }

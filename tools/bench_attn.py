@@ -1,4 +1,4 @@
-"""Micro-benchmark of hdiff_mha_flash_fwd: kernel variants A/B'd in one process, interleaved rounds (dev tool)."""
+"""Micro-benchmark of hdiff_mha_flash_fwd: query tiles per wave (HDIFF_ATT_NQ) A/B'd in one process, interleaved rounds (dev tool)."""
 import ctypes as C
 import os
 import subprocess
@@ -14,7 +14,7 @@ def run(variant, shapes, iters=10):
     # variant is read once per process by the library: run each variant in a child process
     code = f"""
 import os, sys, ctypes as C
-os.environ['HDIFF_ATT_VARIANT'] = '{variant}'
+os.environ['HDIFF_ATT_NQ'] = '{variant}'
 sys.path.insert(0, {ROOT!r})
 import torch, hdiff_amd
 lib = hdiff_amd.lib()
@@ -38,7 +38,7 @@ for (B, Cc, L) in {shapes!r}:
 
 if __name__ == "__main__":
     shapes = [(2, 128, 16384), (2, 256, 16384), (1, 128, 65536)]
-    variants = sys.argv[1:] or ["0", "1", "2"]
+    variants = sys.argv[1:] or ["4", "8"]
     for rnd in range(2):
         for v in variants:
             run(v, shapes)
