@@ -121,7 +121,7 @@ def main():
 
         # locate the dominant kernel: attention launches over the full-resolution token set
         L_full = S * S
-        att_idx = [i for i, (name, _, args) in enumerate(plan.ops) if name == "hdiff_mha_flash_fwd" and args[5] == L_full]
+        att_idx = [i for i, (name, _, args) in enumerate(plan.ops) if name == "hdiff_mha_flash_fwd" and args[6] == L_full]
         events = []
 
         def one_step(timed):

@@ -31,6 +31,18 @@ class ConvDesc(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("x0", C.c_void_p), ("x1", C.c_void_p), ("C0", C.c_int), ("C1", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("gn_scale", C.c_void_p), ("gn_shift", C.c_void_p), ("dy", C.c_void_p),
+        ("Cout", C.c_int), ("CinPad", C.c_int), ("CoutPad", C.c_int), ("OH", C.c_int), ("OW", C.c_int),
+        ("VH", C.c_int), ("VW", C.c_int), ("in_stride", C.c_int),
+        ("out_sy", C.c_int), ("out_oy", C.c_int), ("out_sx", C.c_int), ("out_ox", C.c_int),
+        ("ntaps", C.c_int), ("tap_dy", C.c_int * MAX_TAPS), ("tap_dx", C.c_int * MAX_TAPS),
+    ]
+
+
 _PROTOS = {
     "hdiff_abi_version": (C.c_int, []),
     "hdiff_last_error": (C.c_char_p, []),
@@ -44,7 +56,22 @@ _PROTOS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hdiff_gn_swish_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p]),
-    "hdiff_mha_flash_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hdiff_mha_flash_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hdiff_mha_flash_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p]),
+    "hdiff_conv2d_wgrad_workspace": (C.c_int, [C.POINTER(WgradDesc), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "hdiff_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p, C.c_int, C.c_void_p]),
+    "hdiff_conv_wgrad_unpack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hdiff_gn_swish_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "hdiff_bias_addvec_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hdiff_linear_rows_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hdiff_sq_err_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hdiff_dropout_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "hdiff_mul": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hdiff_linear_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hdiff_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

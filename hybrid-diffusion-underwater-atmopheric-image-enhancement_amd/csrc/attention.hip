@@ -43,7 +43,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int D, int NQ>
 __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                    int C, int L, float qscale) {
+                                                                    float* __restrict__ lse2, int C, int L, float qscale) {
   constexpr int KS = D / 4;                 // k-steps of the QK^T product
   constexpr int MT = (D + 15) / 16;         // 16-row M tiles of the PV product
   constexpr int DP = MT * 16;               // padded V rows
@@ -248,6 +248,8 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float*
     lt += __shfl_xor(lt, 32, 64);
     const float inv = 1.0f / lt;
     const int q = qblk0 + qt * 16 + i16;
+    // log2-domain log-sum-exp of the scaled scores (what the backward kernels recompute P from)
+    if (lse2 != nullptr && q < L && g == 0) lse2[((size_t)b * gridDim.y + head) * L + q] = m_run[qt] + __builtin_amdgcn_logf(lt);
     if (q < L) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -270,37 +272,38 @@ int att_nq_override() {
 }
 
 template <int D, int NQ>
-void launch_v(const float* qkv, float* o, int B, int C, int heads, int L, float qscale, hipStream_t stream) {
+void launch_v(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, hipStream_t stream) {
   dim3 grid(cdiv(L, 64 * NQ), heads, B);
-  hipLaunchKernelGGL((mha_flash_fwd_kernel<D, NQ>), grid, dim3(ATT_THREADS), 0, stream, qkv, o, C, L, qscale);
+  hipLaunchKernelGGL((mha_flash_fwd_kernel<D, NQ>), grid, dim3(ATT_THREADS), 0, stream, qkv, o, lse2, C, L, qscale);
 }
 
 template <int D>
-int launch_d(const float* qkv, float* o, int B, int C, int heads, int L, hipStream_t stream) {
+int launch_d(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, hipStream_t stream) {
   const float qscale = 1.4426950408889634f / sqrtf((float)D);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   int nq = (L >= 512) ? 4 : 1;   // 4 query tiles per wave: 3 waves per SIMD at d_head 16, 2 at d_head 32 (8 tiles measured no faster)
   if (att_nq_override() > 0) nq = att_nq_override();
-  if (nq >= 8) launch_v<D, 8>(qkv, o, B, C, heads, L, qscale, stream);
-  else if (nq >= 4) launch_v<D, 4>(qkv, o, B, C, heads, L, qscale, stream);
-  else launch_v<D, 1>(qkv, o, B, C, heads, L, qscale, stream);
+  if (nq >= 8) launch_v<D, 8>(qkv, o, lse2, B, C, heads, L, qscale, stream);
+  else if (nq >= 4) launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, stream);
+  else launch_v<D, 1>(qkv, o, lse2, B, C, heads, L, qscale, stream);
   HDIFF_CHECK_LAUNCH("mha_flash_fwd_kernel");
   return HDIFF_OK;
 }
 
 }  // namespace
 
-extern "C" int hdiff_mha_flash_fwd(const float* qkv, float* o, int B, int C, int heads, int L, hdiff_stream_t stream) {
+extern "C" int hdiff_mha_flash_fwd(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L,
+                                   hdiff_stream_t stream) {
   HDIFF_CHECK_ARG(qkv && o, "mha_flash_fwd: null pointer");
   HDIFF_CHECK_ARG(B > 0 && L > 0 && heads > 0 && C % heads == 0, "mha_flash_fwd: bad sizes B=%d C=%d heads=%d L=%d", B, C,
                   heads, L);
   const int D = C / heads;
   hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 4: return launch_d<4>(qkv, o, B, C, heads, L, s);
-    case 8: return launch_d<8>(qkv, o, B, C, heads, L, s);
-    case 16: return launch_d<16>(qkv, o, B, C, heads, L, s);
-    case 32: return launch_d<32>(qkv, o, B, C, heads, L, s);
+    case 4: return launch_d<4>(qkv, o, lse2, B, C, heads, L, s);
+    case 8: return launch_d<8>(qkv, o, lse2, B, C, heads, L, s);
+    case 16: return launch_d<16>(qkv, o, lse2, B, C, heads, L, s);
+    case 32: return launch_d<32>(qkv, o, lse2, B, C, heads, L, s);
     default: break;
   }
   hdiff::set_error("mha_flash_fwd: head dim %d not in {4, 8, 16, 32}", D);

@@ -171,6 +171,88 @@ __global__ void axpby_kernel(float a, const float* __restrict__ x, float b, cons
     out[i] = y ? a * x[i] + b * y[i] : a * x[i];   // separate roundings (mul, mul, add): contraction is off in this file
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of linear_rows (autograd of nn.Linear / nn.Embedding, TrainCondition.py:60).  Tiny shapes (B <= 128,
+// K, N <= 512): one thread per output, samples walked in order so the sums are reproducible.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dswishf(float v) {
+  const float sg = 1.0f / (1.0f + __expf(-v));
+  return sg * (1.0f + v * (1.0f - sg));
+}
+
+__global__ void linear_rows_bwd_w_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int n_rows,
+                                         const float* __restrict__ dy, float* __restrict__ dW, float* __restrict__ db, int B,
+                                         int K, int N, int swish_input, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * K) return;
+  const int n = i / K, k = i - n * K;
+  float s = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    int64_t row = idx ? idx[b] : (int64_t)b;
+    if (idx && n_rows > 0) row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+    float v = x[(size_t)row * K + k];
+    if (swish_input) v = swishf(v);
+    const float g = dy[(size_t)b * N + n];
+    s = fmaf(g, v, s);
+    sb += g;
+  }
+  dW[i] = accumulate ? dW[i] + s : s;
+  if (k == 0 && db) db[n] = accumulate ? db[n] + sb : sb;
+}
+
+__global__ void linear_rows_bwd_x_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int n_rows,
+                                         const float* __restrict__ W, const float* __restrict__ dy, float* __restrict__ dx,
+                                         int B, int K, int N, int swish_input, int pad_row) {
+  if (idx) {
+    // gradient of the gathered table rows: one thread per column walks the samples in order (no atomics)
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    for (int b = 0; b < B; ++b) {
+      int64_t row = idx[b];
+      if (n_rows > 0) row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+      if (row == pad_row) continue;     // nn.Embedding(padding_idx): the padding row never receives a gradient
+      float g = 0.f;
+      for (int n = 0; n < N; ++n) g = fmaf(dy[(size_t)b * N + n], W[(size_t)n * K + k], g);
+      if (swish_input) g *= dswishf(x[(size_t)row * K + k]);
+      dx[(size_t)row * K + k] += g;
+    }
+    return;
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * K) return;
+  const int b = i / K, k = i - b * K;
+  float g = 0.f;
+  for (int n = 0; n < N; ++n) g = fmaf(dy[(size_t)b * N + n], W[(size_t)n * K + k], g);
+  if (swish_input) g *= dswishf(x[i]);
+  dx[i] = g;
+}
+
+// d eps_hat of the unreduced squared error: 2 * (a - b) * dloss  (DiffusionCondition.py:45)
+__global__ void sq_err_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dl,
+                                  float* __restrict__ da, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    da[i] = 2.0f * (a[i] - b[i]) * dl[i];
+}
+
+// Bernoulli keep-mask scaled by 1/keep (nn.Dropout in train mode, ModelCondition.py:185), same Philox stream as randn
+__global__ void dropout_mask_kernel(float* __restrict__ out, int64_t n, float keep, uint64_t seed, uint64_t offset) {
+  const float scale = 1.0f / keep;
+  const int64_t nq = (n + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4x32_10(seed, (uint64_t)q, offset, r);
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = (q << 2) + e;
+      if (i < n) out[i] = ((float)(r[e] >> 8) * (1.0f / 16777216.0f) < keep) ? scale : 0.f;
+    }
+  }
+}
+__global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i] * b[i];
+}
+
 inline int grid_for(int64_t n, int per_thread = 1) {
   int64_t blocks = (n / per_thread + 255) / 256;
   if (blocks < 1) blocks = 1;
@@ -262,6 +344,46 @@ int hdiff_axpby(float a, const float* x, float b, const float* y, float* out, in
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, x, b, y, out, n);
   HDIFF_CHECK_LAUNCH("axpby_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_linear_rows_bwd(const float* x, const int64_t* idx, int n_rows, const float* W, const float* dy, float* dx,
+                          float* dW, float* db, int B, int K, int N, int swish_input, int accumulate, int pad_row,
+                          hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(x && W && dy, "linear_rows_bwd: null pointer");
+  HDIFF_CHECK_ARG(B > 0 && K > 0 && N > 0, "linear_rows_bwd: bad sizes");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  if (dW)
+    hipLaunchKernelGGL(linear_rows_bwd_w_kernel, dim3(cdiv(N * K, 256)), dim3(256), 0, (hipStream_t)stream, x, idx, n_rows, dy,
+                       dW, db, B, K, N, swish_input, accumulate);
+  if (dx)
+    hipLaunchKernelGGL(linear_rows_bwd_x_kernel, dim3(cdiv(idx ? K : B * K, 256)), dim3(256), 0, (hipStream_t)stream, x, idx,
+                       n_rows, W, dy, dx, B, K, N, swish_input, pad_row);
+  HDIFF_CHECK_LAUNCH("linear_rows_bwd kernels");
+  return HDIFF_OK;
+}
+
+int hdiff_sq_err_bwd(const float* a, const float* b, const float* dloss, float* da, int64_t n, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(a && b && dloss && da, "sq_err_bwd: null pointer");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(sq_err_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, dloss, da, n);
+  HDIFF_CHECK_LAUNCH("sq_err_bwd_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_dropout_mask(float* out, int64_t n, float keep, uint64_t seed, uint64_t offset, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(out && keep > 0.f && keep <= 1.f, "dropout_mask: bad arguments");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, out, n, keep, seed, offset);
+  HDIFF_CHECK_LAUNCH("dropout_mask_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_mul(const float* a, const float* b, float* out, int64_t n, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(a && b && out, "mul: null pointer");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  HDIFF_CHECK_LAUNCH("mul_kernel");
   return HDIFF_OK;
 }
 

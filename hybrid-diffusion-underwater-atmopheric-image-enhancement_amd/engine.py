@@ -290,7 +290,7 @@ def emit_mha(plan: Plan, P: Dict[str, torch.Tensor], p: str, h: torch.Tensor, B:
     qkv = plan.buf(B, 3 * Cc, H, W)
     plan.conv(h, None, pk_in, P[f"{p}.attn.in_proj_bias"], qkv, B=B, H=H, W=W, VH=H, VW=W)
     o = plan.buf(B, Cc, H, W)
-    plan.call("hdiff_mha_flash_fwd", qkv.data_ptr(), o.data_ptr(), B, Cc, NUM_HEADS, H * W)
+    plan.call("hdiff_mha_flash_fwd", qkv.data_ptr(), o.data_ptr(), None, B, Cc, NUM_HEADS, H * W)
     plan.keep((qkv, o))
     plan.free(qkv)
     y = plan.buf(B, Cc, H, W)

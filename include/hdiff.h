@@ -82,6 +82,33 @@ typedef struct hdiff_conv_desc {
 
 int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream);
 
+/* Weight gradient of hdiff_conv2d_fwd (autograd of the conv weights, TrainCondition.py:60).  Same geometry fields as the
+ * forward descriptor; dy is the gradient of the forward's `out`.  The kernel writes `nsplit` packed partial slabs
+ * dwp[nsplit][ntaps][CinPad][CoutPad] (size from hdiff_conv2d_wgrad_workspace); hdiff_conv_wgrad_unpack sums them in a
+ * fixed order into the PyTorch layout (mode / taps as in hdiff_pack_conv_weight; tap_ky < 0 skips a tap). */
+typedef struct hdiff_conv_wgrad_desc {
+  const float* x0;
+  const float* x1;
+  int C0, C1;
+  int B, H, W;
+  const float* gn_scale;
+  const float* gn_shift;
+  const float* dy;      /* [B][Cout][OH][OW] */
+  int Cout, CinPad, CoutPad;
+  int OH, OW;
+  int VH, VW;
+  int in_stride;
+  int out_sy, out_oy, out_sx, out_ox;
+  int ntaps;
+  int tap_dy[HDIFF_MAX_TAPS];
+  int tap_dx[HDIFF_MAX_TAPS];
+} hdiff_conv_wgrad_desc;
+int hdiff_conv2d_wgrad_workspace(const hdiff_conv_wgrad_desc* d, int* nsplit_out, int64_t* floats_out);
+int hdiff_conv2d_wgrad(const hdiff_conv_wgrad_desc* d, float* dwp, int nsplit, hdiff_stream_t stream);
+int hdiff_conv_wgrad_unpack(const float* dwp, int nsplit, float* dw, int mode, int Cout, int Cin, int KH, int KW, int ntaps,
+                            const int* tap_ky, const int* tap_kx, int CinPad, int CoutPad, int accumulate,
+                            hdiff_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * GroupNorm statistics (K5).  Replaces nn.GroupNorm(32, C) at ModelCondition.py:170,184,249 (the normalisation itself
  * and the Swish at :22-24 are applied inside the consuming convolution's prologue).
@@ -94,6 +121,14 @@ int hdiff_gn_stats(const float* x0, const float* x1, int C0, int C1, int B, int 
 int hdiff_gn_finalize(const float* ws, int B, int C, int G, int nsplit, const float* gamma, const float* beta, float eps,
                       float* scale, float* shift, float* mean_out /*[B][G] or NULL*/, float* rstd_out /*[B][G] or NULL*/,
                       hdiff_stream_t stream);
+/* Backward of GroupNorm + Swish (the conv prologue): dA is the gradient w.r.t. the activated tensor [B][C0+C1][HW];
+ * mean/rstd [B][G] come from hdiff_gn_finalize.  Writes dx0 [B][C0][HW], dx1 [B][C1][HW], dgamma [C], dbeta [C].
+ * ws: 2*B*C + 2*B*G floats. */
+int hdiff_gn_swish_bwd(const float* x0, const float* x1, int C0, int C1, int B, int HW, int G, const float* dA,
+                       const float* mean, const float* rstd, const float* gamma, const float* beta, float* ws, float* dx0,
+                       float* dx1, float* dgamma, float* dbeta, hdiff_stream_t stream);
+/* dvec[b][c] = sum_hw dy[b][c][:] (gradient of the per-sample channel vector) and dbias[c] = sum_b dvec[b][c]; either may be NULL */
+int hdiff_bias_addvec_grad(const float* dy, int B, int C, int HW, float* dvec, float* dbias, hdiff_stream_t stream);
 /* Stand-alone y = swish(x*scale+shift) (used by tests and by the training path). */
 int hdiff_gn_swish_apply(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
                          hdiff_stream_t stream);
@@ -104,7 +139,13 @@ int hdiff_gn_swish_apply(const float* x, const float* scale, const float* shift,
  * [B][3C][L] with rows [Q | K | V], head h owning rows h*d..h*d+d-1 of each third.  o is [B][C][L].
  * Flash style: the L x L score matrix is never materialised.  d = C/heads must be one of 4, 8, 16, 32.
  * ------------------------------------------------------------------------------------------------------------------ */
-int hdiff_mha_flash_fwd(const float* qkv, float* o, int B, int C, int heads, int L, hdiff_stream_t stream);
+int hdiff_mha_flash_fwd(const float* qkv, float* o, float* lse2 /*[B][heads][L] or NULL*/, int B, int C, int heads, int L,
+                        hdiff_stream_t stream);
+/* Backward of the core (autograd of nn.MultiheadAttention, TrainCondition.py:60): dqkv [B][3C][L] from dO [B][C][L].
+ * lse2 is the forward's log2-domain log-sum-exp; delta is a [B][heads][L] workspace (rowsum(dO o O), written here).
+ * P is recomputed, never stored; no atomics (bitwise reproducible). */
+int hdiff_mha_flash_bwd(const float* qkv, const float* o, const float* d_o, const float* lse2, float* delta, float* dqkv,
+                        int B, int C, int heads, int L, hdiff_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Small dense layers (K6, K10).  y[b][j] (+)= bias[j] + sum_k W[j][k] * f(x_row(b)[k]),  f = identity or Swish.
@@ -115,6 +156,13 @@ int hdiff_mha_flash_fwd(const float* qkv, float* o, int B, int C, int heads, int
 int hdiff_linear_rows(const float* x, const int64_t* idx, int n_rows, const float* W, const float* bias, float* y, int B,
                       int K, int N, int swish_input, int accumulate, hdiff_stream_t stream);
 
+/* Backward of hdiff_linear_rows: dW [N][K] (+)= dy^T f(x), db [N] (+)= sum_b dy, and, if dx != NULL, dx = (dy W) o f'(x).
+ * With idx != NULL, dx is the [n_rows][K] gradient of the gathered table and is ACCUMULATED into (zero it first); row
+ * pad_row (>= 0) gets no gradient (nn.Embedding(padding_idx=0), ModelCondition.py:57). */
+int hdiff_linear_rows_bwd(const float* x, const int64_t* idx, int n_rows, const float* W, const float* dy, float* dx,
+                          float* dW, float* db, int B, int K, int N, int swish_input, int accumulate, int pad_row,
+                          hdiff_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Diffusion process (K11-K13), DiffusionFreeGuidence/DiffusionCondition.py.
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -123,6 +171,8 @@ int hdiff_q_sample(const float* x0, const float* noise, const int64_t* t, const 
                    float* xt, int B, int per_sample, hdiff_stream_t stream);
 /* unreduced squared error (:45): loss = (eps_hat - noise)^2 */
 int hdiff_sq_err(const float* a, const float* b, float* out, int64_t n, hdiff_stream_t stream);
+/* its backward: da = 2*(a-b)*dloss */
+int hdiff_sq_err_bwd(const float* a, const float* b, const float* dloss, float* da, int64_t n, hdiff_stream_t stream);
 /* One ancestral step (:74-80, :89-96):
  *   eps = (1+w)*eps_c - w*eps_u  (w is the Python float of the reference; (1+w) is formed in double, then cast) ; mean = coeff1[t]*x - coeff2[t]*eps ; x_next = mean + sigma[t]*z  (z = 0 when t == 0)
  * step_ptr points at the device-resident current time step (int32) so the launch is hipGraph-replayable; when
@@ -138,6 +188,9 @@ int hdiff_step_decrement(int32_t* step_ptr, hdiff_stream_t stream);
 int hdiff_clip(const float* x, float* y, float lo, float hi, int64_t n, hdiff_stream_t stream);
 /* out = a*x + b*y (y may be NULL): bias merges and other weight-preparation arithmetic */
 int hdiff_axpby(float a, const float* x, float b, const float* y, float* out, int64_t n, hdiff_stream_t stream);
+/* nn.Dropout (train mode, ModelCondition.py:185): keep-mask scaled by 1/keep from the Philox stream, and out = a*b */
+int hdiff_dropout_mask(float* out, int64_t n, float keep, uint64_t seed, uint64_t offset, hdiff_stream_t stream);
+int hdiff_mul(const float* a, const float* b, float* out, int64_t n, hdiff_stream_t stream);
 /* standard-normal fill with the same Philox stream (used for in-graph noise and for tests of the generator) */
 int hdiff_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, hdiff_stream_t stream);
 

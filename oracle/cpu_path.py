@@ -102,12 +102,14 @@ def sinusoidal_table(T: int, d_model: int) -> Tensor:
     return torch.stack([torch.sin(ang), torch.cos(ang)], dim=-1).view(T, d_model)
 
 
-def embed_mlp(idx: Tensor, table: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+def embed_mlp(idx: Tensor, table: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor,
+              padding_idx: Optional[int] = None) -> Tensor:
     """Embedding -> Linear -> Swish -> Linear (TimeEmbedding ModelCondition.py:40-49, ConditionalEmbedding :56-65).
 
-    For ConditionalEmbedding the table's row 0 is the padding row (kept at zero by nn.Embedding(padding_idx=0)).
+    For ConditionalEmbedding the table's row 0 is the padding row (kept at zero by nn.Embedding(padding_idx=0), which
+    also gives that row no gradient: pass padding_idx=0 when differentiating).
     """
-    e = table[idx]                                  # gather rows
+    e = torch.nn.functional.embedding(idx, table, padding_idx=padding_idx)   # gather rows
     h = e @ w1.t() + b1
     h = swish(h)
     return h @ w2.t() + b2
@@ -208,7 +210,7 @@ def unet_forward(sd: SD, cfg: UNetConfig, x: Tensor, t: Tensor, labels: Tensor,
                      sd["time_embedding.timembedding.3.weight"], sd["time_embedding.timembedding.3.bias"])
     cemb = embed_mlp(labels, sd["cond_embedding.condEmbedding.0.weight"],
                      sd["cond_embedding.condEmbedding.1.weight"], sd["cond_embedding.condEmbedding.1.bias"],
-                     sd["cond_embedding.condEmbedding.3.weight"], sd["cond_embedding.condEmbedding.3.bias"])
+                     sd["cond_embedding.condEmbedding.3.weight"], sd["cond_embedding.condEmbedding.3.bias"], padding_idx=0)
     if taps is not None:
         taps["temb"], taps["cemb"] = temb, cemb
     h = F.conv2d(x, sd["head.weight"], sd["head.bias"], stride=1, padding=1)

@@ -40,7 +40,7 @@ DEFAULT_SEED = 0
 
 
 def _np(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()      # copy: later in-place updates (clip_grad_norm_, optimizer) must not leak in
 
 
 def _sd_np(sd, prefix="sd/"):

@@ -127,7 +127,7 @@ def test_flash_attention_core(d, L, B):
     o = torch.empty(B, Cc, L, device=DEV)
     lib = _capi.lib()
     d_qkv = qkv.to(DEV)
-    _capi.check(lib.hdiff_mha_flash_fwd(d_qkv.data_ptr(), o.data_ptr(), B, Cc, heads, L,
+    _capi.check(lib.hdiff_mha_flash_fwd(d_qkv.data_ptr(), o.data_ptr(), None, B, Cc, heads, L,
                                         torch.cuda.current_stream().cuda_stream), "mha")
     torch.cuda.synchronize()
     close(o, attention_core_ref(qkv, heads), rel=2e-5, abs_=2e-6, what=f"flash d={d} L={L}")
@@ -144,7 +144,7 @@ def test_flash_attention_online_softmax_rescale():
     qkv[:, Cc:2 * Cc, 500] *= 20.0
     o = torch.empty(B, Cc, L, device=DEV)
     d_qkv = qkv.to(DEV)
-    _capi.check(_capi.lib().hdiff_mha_flash_fwd(d_qkv.data_ptr(), o.data_ptr(), B, Cc, heads, L,
+    _capi.check(_capi.lib().hdiff_mha_flash_fwd(d_qkv.data_ptr(), o.data_ptr(), None, B, Cc, heads, L,
                                                 torch.cuda.current_stream().cuda_stream), "mha")
     close(o, attention_core_ref(qkv, heads), rel=3e-5, abs_=3e-6, what="flash rescale")
 

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
 def test_argument_validation_without_gpu():
     """Entry points validate shapes on the host before any launch (no compute call is made here)."""
     lib = hdiff_amd.lib()
-    assert lib.hdiff_mha_flash_fwd(1, 1, 1, 40, 8, 16, None) == -1            # head dim 5 unsupported
+    assert lib.hdiff_mha_flash_fwd(1, 1, None, 1, 40, 8, 16, None) == -1      # head dim 5 unsupported
     assert b"head dim" in lib.hdiff_last_error()
     assert lib.hdiff_gn_stats(1, None, 48, 0, 1, 16, 32, 1, 1, None) == -1      # 48 channels / 32 groups
     d = _capi.ConvDesc()

@@ -23,12 +23,12 @@ for (B, Cc, L) in {shapes!r}:
     qkv = torch.randn(B, 3 * Cc, L, device='cuda')
     o = torch.empty(B, Cc, L, device='cuda')
     for _ in range(2):
-        lib.hdiff_mha_flash_fwd(qkv.data_ptr(), o.data_ptr(), B, Cc, 8, L, s)
+        lib.hdiff_mha_flash_fwd(qkv.data_ptr(), o.data_ptr(), None, B, Cc, 8, L, s)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range({iters}):
-        lib.hdiff_mha_flash_fwd(qkv.data_ptr(), o.data_ptr(), B, Cc, 8, L, s)
+        lib.hdiff_mha_flash_fwd(qkv.data_ptr(), o.data_ptr(), None, B, Cc, 8, L, s)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / {iters}
     print(f"variant {variant} B={{B}} C={{Cc}} L={{L}}: {{ms:.3f}} ms  {{4.0 * L * L * Cc * B / ms / 1e9:.1f}} TFLOP/s", flush=True)
