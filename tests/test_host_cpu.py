@@ -119,3 +119,42 @@ def test_transposed_conv_phases_cover_every_tap_once():
     assert len(seen) == 25
     t5 = E.conv_taps(5, 2)
     assert (min(t5.dy), max(t5.dy), len(t5.dy)) == (-2, 2, 25)
+
+
+def test_warmup_cosine_lr_sequence_matches_reference():
+    """GradualWarmupScheduler + CosineAnnealingLR stepped per epoch (TrainCondition.py:41-44, 70) vs the reference's sequence."""
+    import warnings
+    from hdiff_amd.Scheduler import GradualWarmupScheduler
+    with open(os.path.join(GOLDEN, "lr_schedule.json")) as fh:
+        ref = json.load(fh)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=ref["base_lr"], weight_decay=1e-4)
+    cos = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=opt, T_max=ref["epochs"], eta_min=0, last_epoch=-1)
+    warm = GradualWarmupScheduler(optimizer=opt, multiplier=ref["multiplier"], warm_epoch=ref["epochs"] // 10,
+                                  after_scheduler=cos)
+    lrs = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(ref["epochs"]):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            warm.step()
+    assert np.allclose(lrs, ref["lr_by_epoch"], rtol=1e-12, atol=0), max(abs(a - b) for a, b in zip(lrs, ref["lr_by_epoch"]))
+
+
+def test_harness_helpers(tmp_path):
+    from hdiff_amd.DiffusionFreeGuidence.TrainCondition import _epoch_indices
+    from hdiff_amd.imageio import ImageDomainFolder, SyntheticDomains, save_image
+    a, b = _epoch_indices(11, 3, 0, 2), _epoch_indices(11, 3, 1, 2)
+    assert len(a) == len(b) == 6 and set(a) | set(b) == set(range(11))         # padded, strided, exhaustive
+    assert _epoch_indices(11, 3, 0, 1) != _epoch_indices(11, 4, 0, 1)
+    ds = SyntheticDomains(8, 16, 3)
+    x, lab = ds[5]
+    assert tuple(x.shape) == (3, 16, 16) and lab == 2 and float(x.abs().max()) <= 1.0
+    assert torch.equal(ds[5][0], x)
+    save_image(torch.rand(5, 3, 16, 16), str(tmp_path / "u" / "a.png"), nrow=4)
+    save_image(torch.rand(3, 3, 16, 16), str(tmp_path / "w" / "b.png"), nrow=4)
+    folder = ImageDomainFolder(str(tmp_path), 8)
+    assert len(folder) == 2 and folder.domains == ["u", "w"]
+    img, lab = folder[1]
+    assert tuple(img.shape) == (3, 8, 8) and lab == 1 and -1.0 <= float(img.min()) and float(img.max()) <= 1.0
