@@ -96,7 +96,7 @@ def _gn_stats(x0, x1, gamma, beta, B, HW):
     Ct = C0 + C1
     if Ct % GN_GROUPS != 0:
         raise RuntimeError(f"Expected number of channels in input to be divisible by num_groups, got {Ct}")
-    nsplit = max(1, min(64, 1024 // (B * GN_GROUPS), HW // 1024))
+    nsplit = max(1, min(32, HW // 4096))     # a function of the plane size only: per-sample results must not depend on B
     ws = torch.empty(B * GN_GROUPS * nsplit * 3, device=dev)
     scale, shift = torch.empty(B, Ct, device=dev), torch.empty(B, Ct, device=dev)
     mean, rstd = torch.empty(B, GN_GROUPS, device=dev), torch.empty(B, GN_GROUPS, device=dev)

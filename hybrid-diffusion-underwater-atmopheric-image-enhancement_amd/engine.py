@@ -224,8 +224,8 @@ class Plan:
         Ct = C0 + C1
         if Ct % GN_GROUPS != 0:
             raise RuntimeError(f"Expected number of channels in input to be divisible by num_groups, got {Ct}")
-        # enough workgroups to stream at HBM rate, but at least ~4K elements per slice
-        nsplit = max(1, min(64, 1024 // (B * GN_GROUPS), HW // 1024))
+        # enough workgroups to stream at HBM rate, at least 4K elements per slice
+        nsplit = max(1, min(32, HW // 4096))     # a function of the plane size only: per-sample results must not depend on B
         ws = self.buf(B * GN_GROUPS * nsplit * 3)
         scale, shift = self.buf(B, Ct), self.buf(B, Ct)
         self.call("hdiff_gn_stats", _ptr(x0), _ptr(x1), C0, C1, B, HW, GN_GROUPS, nsplit, ws.data_ptr())
