@@ -158,3 +158,29 @@ def test_harness_helpers(tmp_path):
     assert len(folder) == 2 and folder.domains == ["u", "w"]
     img, lab = folder[1]
     assert tuple(img.shape) == (3, 8, 8) and lab == 1 and -1.0 <= float(img.min()) and float(img.max()) <= 1.0
+
+
+def test_psnr_ssim_definitions():
+    """metrics.py against a direct evaluation of the published definitions (no skimage in this image)."""
+    from hdiff_amd import metrics as M
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, size=(24, 20, 3)).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-20, 21, size=a.shape), 0, 255).astype(np.uint8)
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    assert abs(M.psnr(a, b, 255) - 10 * np.log10(255.0 ** 2 / mse)) < 1e-12
+    assert M.psnr(a, a, 255) == float("inf") and abs(M.ssim(a, a, 255, channel_axis=2) - 1.0) < 1e-12
+    # brute-force SSIM: every fully interior 7x7 window, sample covariance, per channel, then the mean
+    vals = []
+    x, y = a.astype(np.float64), b.astype(np.float64)
+    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    for c in range(3):
+        for i in range(3, 24 - 3):
+            for j in range(3, 20 - 3):
+                wx, wy = x[i - 3:i + 4, j - 3:j + 4, c].ravel(), y[i - 3:i + 4, j - 3:j + 4, c].ravel()
+                ux, uy = wx.mean(), wy.mean()
+                vx, vy = wx.var(ddof=1), wy.var(ddof=1)
+                vxy = ((wx - ux) * (wy - uy)).sum() / 48.0
+                vals.append(((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2)))
+    assert abs(M.ssim(a, b, 255, channel_axis=2) - np.mean(vals)) < 1e-9
+    p, s = M.batch_psnr_ssim(torch.rand(2, 3, 16, 16), torch.rand(2, 3, 16, 16))
+    assert 0 < p < 20 and -1 <= s <= 1
