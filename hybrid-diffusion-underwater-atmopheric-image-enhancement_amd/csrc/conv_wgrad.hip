@@ -93,8 +93,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradK p) {
 
   float xr[NXS], yr[NYS];
   unsigned xlive = 0;   // bit i: slot i holds a real input element (not zero padding / a missing channel)
-  const int yco = tid >> 2;                 // dY staging: 4 threads per channel row, 32 pixels each
-  const int ypix0 = (tid & 3) * 32;
+  // dY staging: element e = i*256 + tid -> pixel e % 128 (fixed per thread: consecutive lanes read consecutive pixels,
+  // coalesced), channel e / 128 = 2*i + (tid >> 7)
+  const int ypix = tid & (BNP - 1);
+  const int yco0 = tid >> 7;
 
   auto tile_origin = [&](int t, int& b, int& vy0, int& vx0) {
     b = t / p.tiles_per_image;
@@ -122,17 +124,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradK p) {
       }
       xr[i] = v;
     }
-    const int co = co0 + yco;
-    const float* ysrc = p.dy + ((size_t)b * p.Cout + co) * OHW;
+    const int vy = vy0 + (ypix >> p.tw_log2), vx = vx0 + (ypix & TWm1);
+    const bool pix_ok = vy < p.VH && vx < p.VW;
+    const float* ysrc = p.dy + ((size_t)b * p.Cout + co0 + yco0) * OHW +
+                        (pix_ok ? (size_t)(vy * p.out_sy + p.out_oy) * p.OW + (vx * p.out_sx + p.out_ox) : 0);
+    const int co_left = p.Cout - co0 - yco0;      // channel 2*i + yco0 exists iff 2*i < co_left
 #pragma unroll
-    for (int i = 0; i < NYS; ++i) {
-      const int pidx = ypix0 + i;
-      const int vy = vy0 + (pidx >> p.tw_log2), vx = vx0 + (pidx & TWm1);
-      float v = 0.f;
-      if (co < p.Cout && vy < p.VH && vx < p.VW)
-        v = ysrc[(size_t)(vy * p.out_sy + p.out_oy) * p.OW + (vx * p.out_sx + p.out_ox)];
-      yr[i] = v;
-    }
+    for (int i = 0; i < NYS; ++i) yr[i] = (pix_ok && 2 * i < co_left) ? ysrc[(size_t)(2 * i) * OHW] : 0.f;
   };
   auto store_staged = [&](int t) {
     const int b = t / p.tiles_per_image;
@@ -152,7 +150,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradK p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < NYS; ++i) sY[yco * DYROW + ypix0 + i] = yr[i];
+    for (int i = 0; i < NYS; ++i) sY[(2 * i + yco0) * DYROW + ypix] = yr[i];
   };
 
   int t = split;
