@@ -162,6 +162,8 @@ def _refuse_dropout(mod: nn.Module) -> None:
 class UNet(nn.Module):
     """Conditional U-Net denoiser (reference ModelCondition.py:213-276): forward(x[B,3,H,W], t[B], labels[B]) -> eps."""
 
+    MAX_CACHED_PLANS = 2     # launch plans (with their preallocated activations) kept per model, least recently used evicted
+
     def __init__(self, T, num_labels, ch, ch_mult, num_res_blocks, dropout):
         super().__init__()
         tdim = ch * 4
@@ -210,10 +212,14 @@ class UNet(nn.Module):
             self._packed_versions.clear()
             self._plan_ptrs = ptrs
         key = (B, H, W, str(device))
-        up = self._plans.get(key)
+        up = self._plans.pop(key, None)
         if up is None:
+            while len(self._plans) >= self.MAX_CACHED_PLANS:        # a plan owns all its activations: keep few
+                old = next(iter(self._plans))
+                self._plans.pop(old)
+                self._packed_versions.pop(old, None)
             up = E.UNetPlan(_params_of(self), self._shape, B, H, W, device)
-            self._plans[key] = up
+        self._plans[key] = up                                       # most recently used last
         if self._packed_versions.get(key) != versions:
             up.plan.pack_weights()
             self._packed_versions[key] = versions

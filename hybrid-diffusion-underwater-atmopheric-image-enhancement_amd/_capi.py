@@ -14,7 +14,6 @@ LIB_PATH = os.path.join(_HERE, "libhdiff.so")
 CSRC = os.path.join(_HERE, "csrc")
 MAX_TAPS = 25
 
-c_float_p = C.c_void_p  # raw device pointers travel as integers
 _lib = None
 
 
