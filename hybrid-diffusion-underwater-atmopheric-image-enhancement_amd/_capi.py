@@ -27,6 +27,7 @@ class ConvDesc(C.Structure):
         ("VH", C.c_int), ("VW", C.c_int), ("in_stride", C.c_int),
         ("out_sy", C.c_int), ("out_oy", C.c_int), ("out_sx", C.c_int), ("out_ox", C.c_int),
         ("ntaps", C.c_int), ("tap_dy", C.c_int * MAX_TAPS), ("tap_dx", C.c_int * MAX_TAPS),
+        ("splitk_ws", C.c_void_p), ("splitk_floats", C.c_int64),
     ]
 
 
@@ -49,6 +50,7 @@ _PROTOS = {
     "hdiff_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hdiff_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "hdiff_conv2d_fwd_workspace": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int64)]),
     "hdiff_gn_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                  C.c_void_p]),
     "hdiff_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,

@@ -37,6 +37,8 @@ struct ConvK {
   int ntaps, dy_min, dx_min, PH, PW, PWp, PLANE, XFLOATS, WFLOATS;
   int tw_log2, TH, tiles_x;
   int nx, nw;                      // staging slots in use per thread (activation floats, weight float4s)
+  int B, ksplit, chunks_per_split; // split-K over input-channel chunks for small grids (partials -> conv_splitk_reduce)
+  float* partial;                  // [ksplit][B][Cout][VH*VW]
   int tap_off[HDIFF_MAX_TAPS];
 };
 
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z;
+  const int b = blockIdx.z / p.ksplit, kslice = blockIdx.z - b * p.ksplit;
   const int co0 = blockIdx.y * BM;
   const int tile_y = blockIdx.x / p.tiles_x, tile_x = blockIdx.x - tile_y * p.tiles_x;
   const int TWm1 = (1 << p.tw_log2) - 1;
@@ -66,6 +68,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   const int iy0 = vy0 * p.in_stride + p.dy_min, ix0 = vx0 * p.in_stride + p.dx_min;
   const bool has_gn = p.gn_scale != nullptr;
   const size_t HW = (size_t)p.H * p.W;
+  const int c_begin = kslice * p.chunks_per_split * CK;
+  const int c_end = min(p.CinPad, c_begin + p.chunks_per_split * CK);
 
   // ---- per-thread staging slots, fixed for the whole kernel (the patch geometry is the same for every chunk)
   int x_soff[NXS];     // ci*H*W + iy*W + ix inside the chunk's first plane, or -1 when the position is zero padding
@@ -155,12 +159,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   const float* sWh = sW + h * BM + l31;
   const int plane2 = 2 * p.PLANE;
 
-  issue_loads(0);
+  issue_loads(c_begin);
   __syncthreads();     // sG visible
-  for (int c0 = 0; c0 < p.CinPad; c0 += CK) {
+  for (int c0 = c_begin; c0 < c_end; c0 += CK) {
     store_staged(c0);
     __syncthreads();
-    if (c0 + CK < p.CinPad) issue_loads(c0 + CK);
+    if (c0 + CK < c_end) issue_loads(c0 + CK);
 
     // ---- MFMA over (tap, k-pair) steps.  Lane half h supplies k = 2*k2 + h for both operands.
     float a0A, a1A, a0B, a1B, bA[WN], bB[WN];
@@ -197,6 +201,21 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
     const int pidx = (wave * WN + nt) * 32 + l31;
     const int vy = vy0 + (pidx >> p.tw_log2), vx = vx0 + (pidx & TWm1);
     if (vy >= p.VH || vx >= p.VW) continue;
+    if (p.ksplit > 1) {
+      // split-K: raw partial sums over this slice's channels, compact [kslice][b][co][virtual pixel]
+      const size_t vplane = (size_t)p.VH * p.VW;
+      float* dst = p.partial + (((size_t)kslice * p.B + b) * p.Cout) * vplane + (size_t)vy * p.VW + vx;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        if (mt == 1 && !two_m) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (co < p.Cout) dst[(size_t)co * vplane] = acc[mt][nt][r];
+        }
+      }
+      continue;
+    }
     const int oy = vy * p.out_sy + p.out_oy, ox = vx * p.out_sx + p.out_ox;
     const size_t pix = (size_t)oy * p.OW + ox;
     const size_t plane = (size_t)p.OH * p.OW;
@@ -216,6 +235,26 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
         }
       }
     }
+  }
+}
+
+// Sum the split-K partials in slice order and apply the epilogue (bias, per-sample vector, residual).
+__global__ void conv_splitk_reduce_kernel(const ConvK p) {
+  const size_t vplane = (size_t)p.VH * p.VW;
+  const size_t n = (size_t)p.B * p.Cout * vplane;
+  const size_t slice = n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int vpix = (int)(i % vplane);
+    const size_t bc = i / vplane;
+    const int co = (int)(bc % p.Cout), b = (int)(bc / p.Cout);
+    float v = 0.f;
+    for (int k = 0; k < p.ksplit; ++k) v += p.partial[k * slice + i];
+    if (p.bias) v += p.bias[co];
+    if (p.addvec) v += p.addvec[b * p.Cout + co];
+    const int vy = vpix / p.VW, vx = vpix - vy * p.VW;
+    const size_t o = (bc * p.OH + (size_t)(vy * p.out_sy + p.out_oy)) * p.OW + (vx * p.out_sx + p.out_ox);
+    if (p.residual) v += p.residual[o];
+    p.out[o] = v;
   }
 }
 
@@ -260,9 +299,14 @@ int launch(const ConvK& k, int B, size_t lds_bytes, hipStream_t stream) {
   const int BN = 128 * WN;
   const int TW = 1 << k.tw_log2;
   const int tiles_y = cdiv(k.VH, BN / TW);
-  dim3 grid(k.tiles_x * tiles_y, cdiv(k.Cout, BM), B);
+  dim3 grid(k.tiles_x * tiles_y, cdiv(k.Cout, BM), B * k.ksplit);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   hipLaunchKernelGGL((conv_igemm_kernel<WN, CK, NXS, NWS>), grid, dim3(NTHREADS), lds_bytes, stream, k);
+  if (k.ksplit > 1) {
+    const size_t n = (size_t)B * k.Cout * k.VH * k.VW;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, k);
+  }
   HDIFF_CHECK_LAUNCH("conv_igemm_kernel");
   return HDIFF_OK;
 }
@@ -292,7 +336,17 @@ extern "C" int hdiff_pack_conv_weight(const float* w, float* wp, int mode, int C
   return HDIFF_OK;
 }
 
-extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream) {
+namespace {
+
+struct ConvCfg {
+  ConvK k;
+  int WN, CK;
+  size_t lds;
+  int64_t splitk_floats;   // workspace the split-K path wants (0: no split)
+};
+
+// Geometry, tile configuration and split-K policy of one launch (shared by the workspace query and the launcher).
+int configure(const hdiff_conv_desc* d, ConvCfg& c) {
   HDIFF_CHECK_ARG(d && d->x0 && d->wp && d->out, "conv2d_fwd: null pointer");
   HDIFF_CHECK_ARG(d->C1 == 0 || d->x1, "conv2d_fwd: C1 > 0 without x1");
   HDIFF_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= HDIFF_MAX_TAPS, "conv2d_fwd: ntaps %d out of range", d->ntaps);
@@ -305,12 +359,14 @@ extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream)
                   "conv2d_fwd: virtual grid maps outside the output tensor");
   HDIFF_CHECK_ARG((d->gn_scale == nullptr) == (d->gn_shift == nullptr), "conv2d_fwd: gn_scale/gn_shift must come together");
 
-  ConvK k{};
+  ConvK& k = c.k;
+  k = ConvK{};
   k.x0 = d->x0; k.x1 = d->x1; k.C0 = d->C0; k.C1 = d->C1; k.Cin = d->C0 + d->C1; k.H = d->H; k.W = d->W;
   k.wp = d->wp; k.CinPad = d->CinPad; k.CoutPad = d->CoutPad; k.Cout = d->Cout;
   k.bias = d->bias; k.gn_scale = d->gn_scale; k.gn_shift = d->gn_shift; k.addvec = d->addvec; k.residual = d->residual;
   k.out = d->out; k.OH = d->OH; k.OW = d->OW; k.VH = d->VH; k.VW = d->VW; k.in_stride = d->in_stride;
   k.out_sy = d->out_sy; k.out_oy = d->out_oy; k.out_sx = d->out_sx; k.out_ox = d->out_ox; k.ntaps = d->ntaps;
+  k.B = d->B;
 
   int dy_min = d->tap_dy[0], dy_max = d->tap_dy[0], dx_min = d->tap_dx[0], dx_max = d->tap_dx[0];
   for (int t = 1; t < d->ntaps; ++t) {
@@ -321,8 +377,8 @@ extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream)
   }
   k.dy_min = dy_min; k.dx_min = dx_min;
 
-  const int WN = ((long)d->VH * d->VW >= 1024) ? 2 : 1;
-  const int BN = 128 * WN;
+  c.WN = ((long)d->VH * d->VW >= 1024) ? 2 : 1;
+  const int BN = 128 * c.WN;
   int twl = ceil_log2(d->VW);
   if (twl > 5) twl = 5;
   k.tw_log2 = twl;
@@ -344,20 +400,61 @@ extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream)
     const int xfl = (ck * k.PLANE + 3) & ~3;
     return (size_t)(xfl + d->ntaps * ck * BM + 2 * Cin) * sizeof(float);
   };
-  int CK = 0;
-  if (slots_x(8) <= 12 && slots_w(8) <= 5 && lds_for(8) <= 64 * 1024 && (d->C1 == 0 || d->C0 % 8 == 0)) CK = 8;
-  else if (slots_x(4) <= 20 && slots_w(4) <= 7 && lds_for(4) <= 96 * 1024 && (d->C1 == 0 || d->C0 % 4 == 0)) CK = 4;
-  HDIFF_CHECK_ARG(CK != 0, "conv2d_fwd: no kernel configuration fits (taps %d, patch %dx%d, C0 %d)", d->ntaps, k.PH, k.PW,
+  c.CK = 0;
+  if (slots_x(8) <= 12 && slots_w(8) <= 5 && lds_for(8) <= 64 * 1024 && (d->C1 == 0 || d->C0 % 8 == 0)) c.CK = 8;
+  else if (slots_x(4) <= 20 && slots_w(4) <= 7 && lds_for(4) <= 96 * 1024 && (d->C1 == 0 || d->C0 % 4 == 0)) c.CK = 4;
+  HDIFF_CHECK_ARG(c.CK != 0, "conv2d_fwd: no kernel configuration fits (taps %d, patch %dx%d, C0 %d)", d->ntaps, k.PH, k.PW,
                   d->C0);
-  const size_t lds = lds_for(CK);
-  k.XFLOATS = (CK * k.PLANE + 3) & ~3;
-  k.WFLOATS = d->ntaps * CK * BM;
-  k.nx = slots_x(CK);
-  k.nw = slots_w(CK);
+  c.lds = lds_for(c.CK);
+  k.XFLOATS = (c.CK * k.PLANE + 3) & ~3;
+  k.WFLOATS = d->ntaps * c.CK * BM;
+  k.nx = slots_x(c.CK);
+  k.nw = slots_w(c.CK);
 
+  // split-K policy: a small grid with a long channel loop is cut into channel slices (more workgroups, shorter loops).
+  // The decision looks at the whole launch (batch included): a large batch already fills the chip, and splitting it
+  // would only add partial-sum traffic.  Consequence: a sample's last bits may depend on the batch it is computed in
+  // (summation order), never on anything else -- for a fixed shape the result is bitwise reproducible.
+  const int chunks = d->CinPad / c.CK;
+  const long blocks = (long)k.tiles_x * cdiv(d->VH, k.TH) * cdiv(d->Cout, BM) * d->B;
+  int ksplit = 1;
+  if (blocks < 192 && chunks >= 8) {
+    ksplit = (int)((512 + blocks - 1) / blocks);
+    if (ksplit > chunks / 2) ksplit = chunks / 2;
+    if (ksplit > 32) ksplit = 32;
+  }
+  k.chunks_per_split = cdiv(chunks, ksplit);
+  k.ksplit = cdiv(chunks, k.chunks_per_split);
+  c.splitk_floats = (k.ksplit > 1) ? (int64_t)k.ksplit * d->B * d->Cout * d->VH * d->VW : 0;
+  return HDIFF_OK;
+}
+
+}  // namespace
+
+extern "C" int hdiff_conv2d_fwd_workspace(const hdiff_conv_desc* d, int64_t* floats_out) {
+  HDIFF_CHECK_ARG(floats_out, "conv2d_fwd_workspace: null pointer");
+  ConvCfg c;
+  const int rc = configure(d, c);
+  if (rc != HDIFF_OK) return rc;
+  *floats_out = c.splitk_floats;
+  return HDIFF_OK;
+}
+
+extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream) {
+  ConvCfg c;
+  const int rc = configure(d, c);
+  if (rc != HDIFF_OK) return rc;
+  ConvK& k = c.k;
+  if (k.ksplit > 1 && d->splitk_ws != nullptr && d->splitk_floats >= c.splitk_floats) {
+    k.partial = d->splitk_ws;
+  } else {            // no (or too small a) workspace: one slice, the plain epilogue
+    k.ksplit = 1;
+    k.chunks_per_split = d->CinPad / c.CK;
+    k.partial = nullptr;
+  }
   hipStream_t s = (hipStream_t)stream;
-  if (WN == 2 && CK == 8) return launch<2, 8, 12, 5>(k, d->B, lds, s);
-  if (WN == 2 && CK == 4) return launch<2, 4, 20, 7>(k, d->B, lds, s);
-  if (WN == 1 && CK == 8) return launch<1, 8, 12, 5>(k, d->B, lds, s);
-  return launch<1, 4, 20, 7>(k, d->B, lds, s);
+  if (c.WN == 2 && c.CK == 8) return launch<2, 8, 12, 5>(k, d->B, c.lds, s);
+  if (c.WN == 2 && c.CK == 4) return launch<2, 4, 20, 7>(k, d->B, c.lds, s);
+  if (c.WN == 1 && c.CK == 8) return launch<1, 8, 12, 5>(k, d->B, c.lds, s);
+  return launch<1, 4, 20, 7>(k, d->B, c.lds, s);
 }

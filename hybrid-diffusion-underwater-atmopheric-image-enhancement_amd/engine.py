@@ -214,8 +214,16 @@ class Plan:
         d.ntaps = pk.ntaps
         for i in range(pk.ntaps):
             d.tap_dy[i], d.tap_dx[i] = pk.taps.dy[i], pk.taps.dx[i]
-        self.keep((d, x0, x1, pk, bias, out, gn, addvec, residual))
+        need = C.c_int64(0)
+        _capi.check(self.lib.hdiff_conv2d_fwd_workspace(C.byref(d), C.byref(need)), "conv2d_fwd_workspace")
+        ws = None
+        if need.value > 0:               # small grid, long channel loop: split-K partial sums + ordered reduce
+            ws = self.buf(need.value)
+            d.splitk_ws, d.splitk_floats = ws.data_ptr(), need.value
+        self.keep((d, x0, x1, pk, bias, out, gn, addvec, residual, ws))
         self.call("hdiff_conv2d_fwd", C.byref(d))
+        if ws is not None:
+            self.free(ws)
 
     def gn_scale_shift(self, x0: torch.Tensor, x1: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
                        B: int, HW: int) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -78,8 +78,13 @@ typedef struct hdiff_conv_desc {
   int ntaps;
   int tap_dy[HDIFF_MAX_TAPS];
   int tap_dx[HDIFF_MAX_TAPS];
+  /* optional split-K workspace (hdiff_conv2d_fwd_workspace floats): small grids with long channel loops are cut into
+   * channel slices whose partial sums are reduced in a fixed order; NULL = never split */
+  float* splitk_ws;
+  int64_t splitk_floats;
 } hdiff_conv_desc;
 
+int hdiff_conv2d_fwd_workspace(const hdiff_conv_desc* d, int64_t* floats_out);
 int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream);
 
 /* Weight gradient of hdiff_conv2d_fwd (autograd of the conv weights, TrainCondition.py:60).  Same geometry fields as the

@@ -204,9 +204,9 @@ def test_trainer_gradients_and_adamw_step_golden():
     for key in [k for k in d.files if k.startswith("after_step/")]:
         name = key[11:]
         # first AdamW step moves every element by ~lr * g / (|g| + eps): where the clipped gradient is ~1e-8 = eps the
-        # update is ill-conditioned, so bound the worst element by lr and require the bulk to agree tightly
+        # update is ill-conditioned (its sign can flip), so bound the worst element by 2 * lr and require the bulk to agree tightly
         diff = (params[name].detach().cpu() - T(d[key])).abs()
-        assert diff.max().item() < 1e-4 and (diff > 2e-6).float().mean().item() < 0.01, (name, diff.max().item())
+        assert diff.max().item() < 2.5e-4 and (diff > 2e-6).float().mean().item() < 0.01, (name, diff.max().item())
     print("worst relative gradient error", worst)
 
 
