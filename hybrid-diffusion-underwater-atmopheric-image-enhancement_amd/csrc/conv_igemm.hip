@@ -50,7 +50,10 @@ __device__ __forceinline__ float swish_fast(float v) { return v * __builtin_amdg
 //   [registers of chunk c hold the prefetched patch + weight slab]
 //   transform (GroupNorm affine + Swish) and store them to LDS | barrier | issue the global loads of chunk c+1 (they stay
 //   in flight under the MFMAs) | taps x k-pairs of MFMAs, operands prefetched from LDS one step ahead | barrier
-template <int WN, int CK, int NXS, int NWS>
+// SPEC = 1: the 3x3 / stride-1 / 8x32-pixel-tile case (every heavy conv of the U-Net).  Patch geometry is then a
+// compile-time constant (row stride 35, plane 350), the (tap, k-pair) loop is fully unrolled and every LDS operand address
+// is base register + immediate: no VALU instruction is issued between the MFMAs (each one would cost MFMA issue time).
+template <int WN, int CK, int NXS, int NWS, int SPEC>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sX = smem;                       // [CK][PLANE]
@@ -167,16 +170,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
     if (c0 + CK < c_end) issue_loads(c0 + CK);
 
     // ---- MFMA over (tap, k-pair) steps.  Lane half h supplies k = 2*k2 + h for both operands.
-    float a0A, a1A, a0B, a1B, bA[WN], bB[WN];
-    auto frag = [&](int step, float& a0, float& a1, float (&bf)[WN]) {
-      const int tap = step / KH2, k2 = step - tap * KH2;
-      const float* xb = sXh + __builtin_amdgcn_readlane(tapv, tap) + k2 * plane2;
-      const float* wb = sWh + (tap * CK + 2 * k2) * BM;
-      a0 = wb[0];
-      a1 = wb[32];
-#pragma unroll
-      for (int nt = 0; nt < WN; ++nt) bf[nt] = xb[pixoff[nt]];
-    };
     auto mma = [&](float a0, float a1, const float (&bf)[WN]) {
 #pragma unroll
       for (int nt = 0; nt < WN; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[nt], acc[0][nt], 0, 0, 0);
@@ -185,12 +178,38 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
         for (int nt = 0; nt < WN; ++nt) acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[nt], acc[1][nt], 0, 0, 0);
       }
     };
-    frag(0, a0A, a1A, bA);
-    for (int step = 0; step < nsteps; step += 2) {        // nsteps is even (CK/2 is 2 or 4)
-      frag(step + 1, a0B, a1B, bB);
-      mma(a0A, a1A, bA);
-      frag(step + 2 < nsteps ? step + 2 : step, a0A, a1A, bA);
-      mma(a0B, a1B, bB);
+    if constexpr (SPEC == 1) {
+      constexpr int PWP = 35, PL = 350;          // (8 + 2) x (32 + 2) patch, odd row stride
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int k2 = 0; k2 < CK / 2; ++k2) {
+          const int xo = (tap / 3) * PWP + (tap % 3) + k2 * 2 * PL;
+          const int wo = (tap * CK + 2 * k2) * BM;
+          float bf[WN];
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) bf[nt] = sXh[pixoff[nt] + xo];
+          mma(sWh[wo], sWh[wo + 32], bf);
+        }
+      }
+    } else {
+      float a0A, a1A, a0B, a1B, bA[WN], bB[WN];
+      auto frag = [&](int step, float& a0, float& a1, float (&bf)[WN]) {
+        const int tap = step / KH2, k2 = step - tap * KH2;
+        const float* xb = sXh + __builtin_amdgcn_readlane(tapv, tap) + k2 * plane2;
+        const float* wb = sWh + (tap * CK + 2 * k2) * BM;
+        a0 = wb[0];
+        a1 = wb[32];
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) bf[nt] = xb[pixoff[nt]];
+      };
+      frag(0, a0A, a1A, bA);
+      for (int step = 0; step < nsteps; step += 2) {        // nsteps is even (CK/2 is 2 or 4)
+        frag(step + 1, a0B, a1B, bB);
+        mma(a0A, a1A, bA);
+        frag(step + 2 < nsteps ? step + 2 : step, a0A, a1A, bA);
+        mma(a0B, a1B, bB);
+      }
     }
     __syncthreads();
   }
@@ -288,11 +307,11 @@ int ceil_log2(int v) {
   return l;
 }
 
-template <int WN, int CK, int NXS, int NWS>
+template <int WN, int CK, int NXS, int NWS, int SPEC>
 int launch(const ConvK& k, int B, size_t lds_bytes, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WN, CK, NXS, NWS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WN, CK, NXS, NWS, SPEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -301,7 +320,7 @@ int launch(const ConvK& k, int B, size_t lds_bytes, hipStream_t stream) {
   const int tiles_y = cdiv(k.VH, BN / TW);
   dim3 grid(k.tiles_x * tiles_y, cdiv(k.Cout, BM), B * k.ksplit);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  hipLaunchKernelGGL((conv_igemm_kernel<WN, CK, NXS, NWS>), grid, dim3(NTHREADS), lds_bytes, stream, k);
+  hipLaunchKernelGGL((conv_igemm_kernel<WN, CK, NXS, NWS, SPEC>), grid, dim3(NTHREADS), lds_bytes, stream, k);
   if (k.ksplit > 1) {
     const size_t n = (size_t)B * k.Cout * k.VH * k.VW;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
@@ -453,8 +472,12 @@ extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream)
     k.partial = nullptr;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (c.WN == 2 && c.CK == 8) return launch<2, 8, 12, 5>(k, d->B, c.lds, s);
-  if (c.WN == 2 && c.CK == 4) return launch<2, 4, 20, 7>(k, d->B, c.lds, s);
-  if (c.WN == 1 && c.CK == 8) return launch<1, 8, 12, 5>(k, d->B, c.lds, s);
-  return launch<1, 4, 20, 7>(k, d->B, c.lds, s);
+  // the specialised 3x3 path: standard taps in row-major order, stride 1, 8x32 tile (patch stride 35, plane 350)
+  bool spec = c.WN == 2 && c.CK == 8 && d->ntaps == 9 && d->in_stride == 1 && k.tw_log2 == 5 && k.PWp == 35 && k.PLANE == 350;
+  for (int t = 0; spec && t < 9; ++t) spec = k.tap_off[t] == (t / 3) * 35 + (t % 3);
+  if (spec) return launch<2, 8, 12, 5, 1>(k, d->B, c.lds, s);
+  if (c.WN == 2 && c.CK == 8) return launch<2, 8, 12, 5, 0>(k, d->B, c.lds, s);
+  if (c.WN == 2 && c.CK == 4) return launch<2, 4, 20, 7, 0>(k, d->B, c.lds, s);
+  if (c.WN == 1 && c.CK == 8) return launch<1, 8, 12, 5, 0>(k, d->B, c.lds, s);
+  return launch<1, 4, 20, 7, 0>(k, d->B, c.lds, s);
 }
