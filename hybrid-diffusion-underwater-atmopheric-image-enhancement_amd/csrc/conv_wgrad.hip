@@ -44,6 +44,9 @@ struct WgradK {
 
 __device__ __forceinline__ float swish_fast_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
+// ROWS = input stride (1 or 2) when the tile is 4 rows x 32 pixels (each wave then owns one tile row and every LDS operand
+// address in the pixel loop is base + immediate: no VALU between the MFMAs); ROWS = 0 is the generic tile shape.
+template <int ROWS>
 __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sY = smem;                          // [BM][DYROW]; reused for the cross-wave reduction
@@ -163,18 +166,36 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradK p) {
 
     // each wave takes a quarter of the tile's pixels; lane half h supplies pixel k = 2*kk + h
     const int kbeg = wave * (BNP / 4);
-#pragma unroll 4
-    for (int kk = 0; kk < BNP / 8; ++kk) {
-      const int k = kbeg + 2 * kk + h;
-      const int pixoff = ((k >> p.tw_log2) * p.PWp + (k & TWm1)) * p.in_stride;
-      const float a0 = sY[l31 * DYROW + k];
-      const float a1 = sY[(32 + l31) * DYROW + k];
+    if constexpr (ROWS > 0) {
+      const float* yb = sY + l31 * DYROW + kbeg + h;
+      const float* xb = sX + (wave * p.PWp + h) * ROWS;          // tile row `wave`, pixel h
 #pragma unroll
-      for (int nt = 0; nt < MAXNT; ++nt) {
-        if (nt < p.nt_used) {
-          const float bv = sX[coloff[nt] + pixoff];
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][nt], 0, 0, 0);
-          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][nt], 0, 0, 0);
+      for (int kk = 0; kk < BNP / 8; ++kk) {
+        const float a0 = yb[2 * kk];
+        const float a1 = yb[32 * DYROW + 2 * kk];
+#pragma unroll
+        for (int nt = 0; nt < MAXNT; ++nt) {
+          if (nt < p.nt_used) {
+            const float bv = xb[coloff[nt] + 2 * kk * ROWS];
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][nt], 0, 0, 0);
+            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][nt], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int kk = 0; kk < BNP / 8; ++kk) {
+        const int k = kbeg + 2 * kk + h;
+        const int pixoff = ((k >> p.tw_log2) * p.PWp + (k & TWm1)) * p.in_stride;
+        const float a0 = sY[l31 * DYROW + k];
+        const float a1 = sY[(32 + l31) * DYROW + k];
+#pragma unroll
+        for (int nt = 0; nt < MAXNT; ++nt) {
+          if (nt < p.nt_used) {
+            const float bv = sX[coloff[nt] + pixoff];
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][nt], 0, 0, 0);
+            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][nt], 0, 0, 0);
+          }
         }
       }
     }
@@ -310,13 +331,19 @@ extern "C" int hdiff_conv2d_wgrad(const hdiff_conv_wgrad_desc* d, float* dwp, in
 
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   dim3 grid(cdiv(d->Cout, BM), cdiv(d->CinPad, k.CKW), nsplit);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(NTHREADS), lds, (hipStream_t)stream, k);
+  if (k.tw_log2 == 5 && d->in_stride == 1)
+    hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(NTHREADS), lds, (hipStream_t)stream, k);
+  else if (k.tw_log2 == 5 && d->in_stride == 2)
+    hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(NTHREADS), lds, (hipStream_t)stream, k);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<0>, grid, dim3(NTHREADS), lds, (hipStream_t)stream, k);
   HDIFF_CHECK_LAUNCH("conv_wgrad_kernel");
   return HDIFF_OK;
 }
