@@ -182,7 +182,9 @@ def main():
                     traffic = json.load(open(prof)).get(f"mha_flash_fwd_L{L_full}_B{2 * B}")
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": f"mha_flash_fwd_kernel<16,4> L={L_full} d_head=16 heads=8 batch={2 * B}",
+            roof = {"bound": "mfma",
+                    "kernel": f"hdiff_mha_flash_fwd = mha_flash_fwd_fast_kernel<16,4> + overflow-check pass, L={L_full} d_head=16 "
+                              f"heads=8 batch={2 * B}",
                     "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg, 3), "launches_timed": len(att_ms),

@@ -43,7 +43,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int D, int NQ>
 __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                    float* __restrict__ lse2, int C, int L, float qscale) {
+                                                                    float* __restrict__ lse2, int C, int L, float qscale, int check) {
   constexpr int KS = D / 4;                 // k-steps of the QK^T product
   constexpr int MT = (D + 15) / 16;         // 16-row M tiles of the PV product
   constexpr int DP = MT * 16;               // padded V rows
@@ -65,6 +65,14 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float*
   const float* vbase = kbase + (size_t)C * L;
   const bool vec_ok = (L & 3) == 0;
   const int ntiles = (L + KT - 1) / KT;
+
+  if (check) {
+    // second pass behind mha_flash_fwd_fast_kernel: only query blocks it flagged (NaN in their first output row) are
+    // recomputed here with the overflow-proof running max; everything else exits at once
+    const int q = blockIdx.x * QB + tid;
+    const bool flagged = (tid < QB) && (q < L) && isnan(out[((size_t)b * C + (size_t)head * D) * L + q]);
+    if (!__syncthreads_or(flagged)) return;
+  }
 
   // zero the padded V rows once (D < 16)
   if (DP > D) {
@@ -262,6 +270,193 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float*
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast path for full-length tiles (L % 64 == 0): FIXED softmax reference point.
+// The running max is taken from the first key tile only and never moved: p = exp2(s - m1).  fp32 keeps full relative
+// precision at any scale, so this is exact as long as no later score exceeds m1 by ~2^7 (88 nats) -- and then the
+// product overflows to inf, which is detected from the row sum at the end: the wave poisons its outputs with NaN and the
+// overflow-proof kernel above, launched right behind with check = 1, recomputes just those query blocks.
+// What it buys: the hot loop has no max, no compare, no branch and no subtraction -- -m1 is the initial accumulator of the
+// QK^T MFMA chain -- so per 16x16 score tile the VALU work is 4 v_exp_f32 + 2 v_pk_add_f32 per lane and nothing else
+// (on gfx950 every VALU instruction is fp32-MFMA issue time).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr float FAST_OVERFLOW_LIMIT = 1.2379400e27f;   // 2^90: a row sum at or above it (or NaN) -> recompute safely
+
+template <int D, int NQ>
+__global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const float* __restrict__ qkv,
+                                                                         float* __restrict__ out,
+                                                                         float* __restrict__ lse2, int C, int L,
+                                                                         float qscale) {
+  constexpr int KS = D / 4;
+  constexpr int MT = (D + 15) / 16;
+  constexpr int DP = MT * 16;
+  constexpr int NV4 = 2 * D * (KT / 4);
+  constexpr int NLD = (NV4 + ATT_THREADS - 1) / ATT_THREADS;
+  constexpr int QB = 4 * 16 * NQ;
+  constexpr int N_QK = 4 * KS;
+  constexpr int N_PV = 16 * MT;
+
+  __shared__ __attribute__((aligned(16))) float sK[2][D * KROW];
+  __shared__ __attribute__((aligned(16))) float sV[2][DP * KROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int qblk0 = blockIdx.x * QB + wave * (16 * NQ);
+  const float* qbase = qkv + ((size_t)b * 3 * C + (size_t)head * D) * L;
+  const float* kbase = qbase + (size_t)C * L;
+  const float* vbase = kbase + (size_t)C * L;
+  const int ntiles = L / KT;
+
+  if (DP > D) {
+    for (int idx = tid; idx < 2 * (DP - D) * KROW; idx += ATT_THREADS) {
+      const int bufi = idx / ((DP - D) * KROW), rem = idx - bufi * (DP - D) * KROW;
+      sV[bufi][D * KROW + rem] = 0.f;
+    }
+  }
+
+  float qf[NQ][KS];
+#pragma unroll
+  for (int qt = 0; qt < NQ; ++qt) {
+    const int q = qblk0 + qt * 16 + i16;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[qt][s] = (q < L) ? qbase[(size_t)(4 * s + g) * L + q] * qscale : 0.f;
+  }
+
+  float4 stage[NLD];
+  auto stage_load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * ATT_THREADS;
+      if (idx < NV4) {
+        const int row = idx >> 4, seg = idx & 15;
+        const float* src = (row < D ? kbase + (size_t)row * L : vbase + (size_t)(row - D) * L) + t * KT + seg * 4;
+        stage[i] = *reinterpret_cast<const float4*>(src);
+      }
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * ATT_THREADS;
+      if (idx < NV4) {
+        const int row = idx >> 4, seg = idx & 15;
+        float* dst = (row < D) ? &sK[buf][row * KROW + seg * 4] : &sV[buf][(row - D) * KROW + seg * 4];
+        *reinterpret_cast<float4*>(dst) = stage[i];
+      }
+    }
+  };
+
+  f32x4 O[MT][NQ];
+  f32x4 negm4[NQ];       // -m1 of the wave's queries, splat over a 4-register tuple: the C operand that starts each QK^T chain
+  float l_run[NQ];
+#pragma unroll
+  for (int qt = 0; qt < NQ; ++qt) {
+    l_run[qt] = 0.f;
+    negm4[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) O[mt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  auto do_tile = [&](auto first_tag, int buf) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    float kf[4][KS];
+    float vf[4][MT][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) kf[ks][s] = sK[buf][(4 * s + g) * KROW + ks * 16 + i16];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float4 v4 = *reinterpret_cast<const float4*>(&sV[buf][(mt * 16 + i16) * KROW + ks * 16 + 4 * g]);
+        vf[ks][mt][0] = v4.x; vf[ks][mt][1] = v4.y; vf[ks][mt][2] = v4.z; vf[ks][mt][3] = v4.w;
+      }
+    }
+    f32x4 S[2][4];
+    f32x4 P[4];
+    auto qk_mfma = [&](int qt, int i) {
+      const int s = i >> 2, ks = i & 3;
+      // the chain starts from -m1 (zero on the first tile), so the accumulator already holds s - m1
+      S[qt & 1][ks] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks][s], qf[qt][s], s == 0 ? negm4[qt] : S[qt & 1][ks], 0, 0, 0);
+    };
+    auto pv_mfma = [&](int qt, int i) {
+      const int mt = i % MT, j = i / MT, ks = j >> 2, r = j & 3;
+      O[mt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[ks][mt][r], P[ks][r], O[mt][qt], 0, 0, 0);
+    };
+    auto softmax = [&](int qt) {
+      f32x4(&Sq)[4] = S[qt & 1];
+      if (FIRST) {
+        float tm = fmaxf(fmaxf(Sq[0][0], Sq[0][1]), fmaxf(Sq[0][2], Sq[0][3]));
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) tm = fmaxf(tm, fmaxf(fmaxf(Sq[ks][0], Sq[ks][1]), fmaxf(Sq[ks][2], Sq[ks][3])));
+        tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        const float nm = -tm;
+        negm4[qt] = f32x4{nm, nm, nm, nm};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) Sq[ks] += negm4[qt];
+      }
+      f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x2 pa = {__builtin_amdgcn_exp2f(Sq[ks][0]), __builtin_amdgcn_exp2f(Sq[ks][1])};
+        const f32x2 pc = {__builtin_amdgcn_exp2f(Sq[ks][2]), __builtin_amdgcn_exp2f(Sq[ks][3])};
+        sum2 += pa;
+        sum2 += pc;
+        P[ks] = f32x4{pa.x, pa.y, pc.x, pc.y};
+      }
+      l_run[qt] += sum2.x + sum2.y;
+    };
+#pragma unroll
+    for (int i = 0; i < N_QK; ++i) qk_mfma(0, i);
+#pragma unroll
+    for (int qt = 0; qt < NQ; ++qt) {
+      softmax(qt);
+      constexpr int NMAX = (N_QK > N_PV) ? N_QK : N_PV;
+#pragma unroll
+      for (int i = 0; i < NMAX; ++i) {
+        if (i < N_PV) pv_mfma(qt, i);
+        if (qt + 1 < NQ && i < N_QK) qk_mfma(qt + 1, i);
+      }
+    }
+  };
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    stage_load((t + 1 < ntiles) ? t + 1 : t);
+    if (t == 0) do_tile(std::true_type{}, buf);
+    else do_tile(std::false_type{}, buf);
+    stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* obase = out + ((size_t)b * C + (size_t)head * D) * L;
+#pragma unroll
+  for (int qt = 0; qt < NQ; ++qt) {
+    float lt = l_run[qt];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const bool bad = !(lt < FAST_OVERFLOW_LIMIT);            // overflow (or NaN): hand this query block to the safe kernel
+    const float inv = bad ? __builtin_nanf("") : 1.0f / lt;
+    const int q = qblk0 + qt * 16 + i16;
+    if (lse2 != nullptr && q < L && g == 0)
+      lse2[((size_t)b * gridDim.y + head) * L + q] = bad ? __builtin_nanf("") : __builtin_amdgcn_logf(lt) - negm4[qt][0];
+    if (q < L) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = mt * 16 + 4 * g + r;
+          if (d < D) obase[(size_t)d * L + q] = O[mt][qt][r] * inv;
+        }
+    }
+  }
+}
+
 int att_nq_override() {
   static int v = -1;
   if (v < 0) {
@@ -271,10 +466,20 @@ int att_nq_override() {
   return v;
 }
 
+int att_fast_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("HDIFF_ATT_FAST");   // dev knob: 0 disables the fixed-reference fast path
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
 template <int D, int NQ>
-void launch_v(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, hipStream_t stream) {
+void launch_v(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, int check,
+              hipStream_t stream) {
   dim3 grid(cdiv(L, 64 * NQ), heads, B);
-  hipLaunchKernelGGL((mha_flash_fwd_kernel<D, NQ>), grid, dim3(ATT_THREADS), 0, stream, qkv, o, lse2, C, L, qscale);
+  hipLaunchKernelGGL((mha_flash_fwd_kernel<D, NQ>), grid, dim3(ATT_THREADS), 0, stream, qkv, o, lse2, C, L, qscale, check);
 }
 
 template <int D>
@@ -283,9 +488,14 @@ int launch_d(const float* qkv, float* o, float* lse2, int B, int C, int heads, i
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   int nq = (L >= 512) ? 4 : 1;   // 4 query tiles per wave: 3 waves per SIMD at d_head 16, 2 at d_head 32 (8 tiles measured no faster)
   if (att_nq_override() > 0) nq = att_nq_override();
-  if (nq >= 8) launch_v<D, 8>(qkv, o, lse2, B, C, heads, L, qscale, stream);
-  else if (nq >= 4) launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, stream);
-  else launch_v<D, 1>(qkv, o, lse2, B, C, heads, L, qscale, stream);
+  if (nq == 4 && D <= 16 && L % KT == 0 && att_fast_enabled()) {   // d_head 32: 230 registers (2 waves/SIMD), measured no faster
+    // fixed-reference fast kernel, then the overflow-proof kernel in check mode (exits at once unless flagged)
+    dim3 grid(cdiv(L, 256), heads, B);
+    hipLaunchKernelGGL((mha_flash_fwd_fast_kernel<D, 4>), grid, dim3(ATT_THREADS), 0, stream, qkv, o, lse2, C, L, qscale);
+    launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, 1, stream);
+  } else if (nq >= 8) launch_v<D, 8>(qkv, o, lse2, B, C, heads, L, qscale, 0, stream);
+  else if (nq >= 4) launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, 0, stream);
+  else launch_v<D, 1>(qkv, o, lse2, B, C, heads, L, qscale, 0, stream);
   HDIFF_CHECK_LAUNCH("mha_flash_fwd_kernel");
   return HDIFF_OK;
 }

@@ -149,6 +149,32 @@ def test_flash_attention_online_softmax_rescale():
     close(o, attention_core_ref(qkv, heads), rel=3e-5, abs_=3e-6, what="flash rescale")
 
 
+def test_flash_attention_fixed_reference_overflow_falls_back():
+    """The fast kernel keeps the first tile's max as its only softmax reference; a later key that beats it by > 2^7 (log2
+    units) overflows exp2 on purpose -> the affected query blocks are poisoned and recomputed by the overflow-proof
+    kernel.  Spike keys hard enough to force that, in some heads / query blocks only, and compare everything."""
+    g = torch.Generator().manual_seed(8)
+    heads, d, L, B = 8, 16, 2048, 2
+    Cc = heads * d
+    qkv = torch.randn(B, 3 * Cc, L, generator=g)
+    qkv[0, Cc + 2 * d:Cc + 3 * d, 700] *= 90.0          # head 2 of sample 0: key 700 (tile 10) dominates by hundreds of bits
+    qkv[1, Cc + 5 * d:Cc + 6 * d, 1999] *= 150.0        # head 5 of sample 1: the very last tile
+    qkv[1, 0 * d:1 * d, 300:364] *= 40.0                # huge queries in one 64-query stretch of head 0
+    o = torch.empty(B, Cc, L, device=DEV)
+    lse = torch.empty(B, heads, L, device=DEV)
+    d_qkv = qkv.to(DEV)
+    _capi.check(_capi.lib().hdiff_mha_flash_fwd(d_qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, Cc, heads, L,
+                                                torch.cuda.current_stream().cuda_stream), "mha")
+    ref = attention_core_ref(qkv, heads)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    close(o, ref, rel=3e-5, abs_=3e-6, what="flash overflow fallback")
+    # log-sum-exp (log2 domain) against fp64
+    q, k, _ = [z.reshape(B, heads, d, L).transpose(2, 3).double() for z in qkv.split(Cc, dim=1)]
+    s2 = (q @ k.transpose(2, 3)) / math.sqrt(d) * math.log2(math.e)
+    ref_lse = torch.logsumexp(s2 * math.log(2.0), dim=-1) / math.log(2.0)
+    close(lse, ref_lse.float(), rel=1e-5, abs_=1e-4, what="lse2")
+
+
 def test_linear_rows_and_gather():
     g = torch.Generator().manual_seed(1)
     table = torch.randn(20, 128, generator=g)
