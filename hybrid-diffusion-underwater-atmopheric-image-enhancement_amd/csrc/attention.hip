@@ -324,15 +324,15 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
     for (int s = 0; s < KS; ++s) qf[qt][s] = (q < L) ? qbase[(size_t)(4 * s + g) * L + q] * qscale : 0.f;
   }
 
-  float4 stage[NLD];
+  f32x4 stage[NLD];
   auto stage_load = [&](int t) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + i * ATT_THREADS;
-      if (idx < NV4) {
+      if (NV4 % ATT_THREADS == 0 || idx < NV4) {
         const int row = idx >> 4, seg = idx & 15;
         const float* src = (row < D ? kbase + (size_t)row * L : vbase + (size_t)(row - D) * L) + t * KT + seg * 4;
-        stage[i] = *reinterpret_cast<const float4*>(src);
+        stage[i] = *reinterpret_cast<const f32x4*>(src);
       }
     }
   };
@@ -340,20 +340,20 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + i * ATT_THREADS;
-      if (idx < NV4) {
+      if (NV4 % ATT_THREADS == 0 || idx < NV4) {
         const int row = idx >> 4, seg = idx & 15;
         float* dst = (row < D) ? &sK[buf][row * KROW + seg * 4] : &sV[buf][(row - D) * KROW + seg * 4];
-        *reinterpret_cast<float4*>(dst) = stage[i];
+        *reinterpret_cast<f32x4*>(dst) = stage[i];
       }
     }
   };
 
   f32x4 O[MT][NQ];
   f32x4 negm4[NQ];       // -m1 of the wave's queries, splat over a 4-register tuple: the C operand that starts each QK^T chain
-  float l_run[NQ];
+  f32x2 l_run[NQ];
 #pragma unroll
   for (int qt = 0; qt < NQ; ++qt) {
-    l_run[qt] = 0.f;
+    l_run[qt] = f32x2{0.f, 0.f};
     negm4[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) O[mt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
         sum2 += pc;
         P[ks] = f32x4{pa.x, pa.y, pc.x, pc.y};
       }
-      l_run[qt] += sum2.x + sum2.y;
+      l_run[qt] += sum2;    // packed running sums (tile sums first: shorter rounding chains), folded after the last tile
     };
 #pragma unroll
     for (int i = 0; i < N_QK; ++i) qk_mfma(0, i);
@@ -425,11 +425,15 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
   stage_load(0);
   stage_store(0);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  // the first tile (which fixes the reference point) is peeled, so the steady-state loop body is branch-free
+  stage_load(ntiles > 1 ? 1 : 0);
+  do_tile(std::true_type{}, 0);
+  stage_store(1);
+  __syncthreads();
+  for (int t = 1; t < ntiles; ++t) {
     const int buf = t & 1;
     stage_load((t + 1 < ntiles) ? t + 1 : t);
-    if (t == 0) do_tile(std::true_type{}, buf);
-    else do_tile(std::false_type{}, buf);
+    do_tile(std::false_type{}, buf);
     stage_store(buf ^ 1);
     __syncthreads();
   }
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
   float* obase = out + ((size_t)b * C + (size_t)head * D) * L;
 #pragma unroll
   for (int qt = 0; qt < NQ; ++qt) {
-    float lt = l_run[qt];
+    float lt = l_run[qt].x + l_run[qt].y;
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
     const bool bad = !(lt < FAST_OVERFLOW_LIMIT);            // overflow (or NaN): hand this query block to the safe kernel
