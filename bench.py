@@ -30,6 +30,7 @@ MODEL = dict(T=1000, num_labels=10, ch=128, ch_mult=[1, 2, 2, 2], num_res_blocks
 BETA = (1e-4, 0.02)
 GUIDANCE_W = 1.8
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak (= fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2516.6    # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 # algorithmic FLOPs per sample per UNet forward (torch flop counter on the reference UNet)
 FWD_GFLOP = {64: 74.0, 128: 529.6, 256: 5857.4, 512: 83254.1}
 
@@ -42,6 +43,9 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--contract", choices=["f32", "bf16x3"], default="f32",
+                    help="attention contractions: fp32-input MFMA (default) or the fp32-class three-piece bf16 split")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed in `value`) run in the other contraction mode")
     ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph instead of eager launches "
                     "(no per-kernel events inside the timed region)")
     return ap.parse_args()
@@ -101,6 +105,7 @@ def main():
     lib = hdiff_amd.lib()
 
     S, B, K, Wm = a.size, a.batch, a.steps, a.warmup
+    hdiff_amd.set_contraction_mode(a.contract)
     torch.manual_seed(0)                              # same weights on every rank (replicated model)
     model = UNet(**MODEL).eval().to(dev)
     sampler = GaussianDiffusionSampler(model, BETA[0], BETA[1], MODEL["T"], w=GUIDANCE_W).to(dev)
@@ -156,6 +161,25 @@ def main():
         assert int(sp.nan_flag.item()) == 0, "nan in tensor."
         assert int(sp.step.item()) == MODEL["T"] - 1 - (K + Wm)
 
+        # the other contraction mode, reported beside the headline (never part of `value`)
+        alt = None
+        if world == 1 and not a.no_alt and not a.graph:
+            other = "bf16x3" if a.contract == "f32" else "f32"
+            hdiff_amd.set_contraction_mode(other)
+            one_step(False)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(K):
+                one_step(False)
+            torch.cuda.synchronize(dev)
+            dt_alt = (time.perf_counter() - t1) / K
+            hdiff_amd.set_contraction_mode(a.contract)
+            assert int(sp.nan_flag.item()) == 0, "nan in tensor."
+            alt = {"contract": other, "ms_per_step": dt_alt * 1e3, "denoising_steps_per_s": 1.0 / dt_alt,
+                   "note": "same workload with the attention contractions in the other mode; bf16x3 = every fp32 operand as "
+                           "three bf16 pieces, six products on the bf16 MFMA, fp32 accumulate (fp32-class error, "
+                           "tests/test_gpu_ops.py::test_flash_attention_split_bf16_is_fp32_class)"}
+
     if dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
@@ -182,11 +206,15 @@ def main():
                     traffic = json.load(open(prof)).get(f"mha_flash_fwd_L{L_full}_B{2 * B}")
                 except Exception:
                     traffic = None
+            if a.contract == "f32":
+                kname, peak = "mha_flash_fwd_fast_kernel<16,4>", PEAK_F32_MFMA_TFLOPS
+            else:   # six bf16 products per fp32 product: the scheme's fp32-equivalent ceiling is the bf16 dense peak / 6
+                kname, peak = "mha_flash_fwd_x3_kernel<16,4> (3xbf16 split, peak = bf16 dense peak / 6)", PEAK_BF16_MFMA_TFLOPS / 6
             roof = {"bound": "mfma",
-                    "kernel": f"hdiff_mha_flash_fwd = mha_flash_fwd_fast_kernel<16,4> + overflow-check pass, L={L_full} d_head=16 "
+                    "kernel": f"hdiff_mha_flash_fwd = {kname} + overflow-check pass, L={L_full} d_head=16 "
                               f"heads=8 batch={2 * B}",
-                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg, 3), "launches_timed": len(att_ms),
                     "algorithmic_flop_per_launch": flops_per_launch}
         step_tflop = 2 * B * FWD_GFLOP.get(S, 0.0) / 1e3
@@ -194,14 +222,16 @@ def main():
             "metric": "denoising-steps/sec (256x256, T=1000)" if S == 256 else f"denoising-steps/sec ({S}x{S}, T=1000)",
             "value": world * K / elapsed, "unit": "denoising-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if a.contract == "f32" else "f32 (attention products as 3xbf16 split, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"CFG-DDPM sampling, {S}x{S}, T=1000 linear schedule (1e-4..0.02), w={GUIDANCE_W}, "
                                    f"batch {B}/GPU (2x{B} UNet forwards per step), default UNet ch=128 ch_mult=[1,2,2,2] "
                                    "num_res_blocks=2 (47.8 M params), random-init weights, in-kernel Philox noise",
                        "batch_per_gpu": B, "image": S, "launch": "hipGraph replay" if a.graph else "eager launches",
                        "sample_steps_per_s": world * K * B / elapsed,
                        "algorithmic_tflop_per_step_per_gpu": step_tflop,
-                       "whole_step_tflops_per_gpu": step_tflop / (elapsed / K) if elapsed > 0 else None},
+                       "whole_step_tflops_per_gpu": step_tflop / (elapsed / K) if elapsed > 0 else None,
+                       "attention_contract": a.contract, "other_contract_mode": alt},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

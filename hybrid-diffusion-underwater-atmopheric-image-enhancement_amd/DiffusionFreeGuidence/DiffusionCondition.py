@@ -112,10 +112,10 @@ class _SamplerPlan:
         return p
 
     def variant(self, inject_noise: bool, seed: int) -> E.Plan:
-        key = (inject_noise, seed if not inject_noise else 0)
+        key = (inject_noise, seed if not inject_noise else 0, _capi.lib().hdiff_get_contraction_mode())
         if key not in self._variants:
             self.seed = seed
-            self._variants.clear()          # a graph bakes its seed: keep one live variant
+            self._variants.clear()          # a graph bakes its seed (and the contraction mode): keep one live variant
             self._variants[key] = self._build(inject_noise)
         return self._variants[key]
 

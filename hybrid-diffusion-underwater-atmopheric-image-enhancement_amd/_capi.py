@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhdiff.so")
+LIB_PATH = os.environ.get("HDIFF_LIB", os.path.join(_HERE, "libhdiff.so"))   # HDIFF_LIB: dev override (A/B builds)
 CSRC = os.path.join(_HERE, "csrc")
 MAX_TAPS = 25
 
@@ -47,6 +47,8 @@ _PROTOS = {
     "hdiff_abi_version": (C.c_int, []),
     "hdiff_last_error": (C.c_char_p, []),
     "hdiff_device_count": (C.c_int, []),
+    "hdiff_set_contraction_mode": (C.c_int, [C.c_int]),
+    "hdiff_get_contraction_mode": (C.c_int, []),
     "hdiff_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hdiff_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),

@@ -41,4 +41,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+int contraction_mode();   // HDIFF_CONTRACT_*
+// attention_x3.hip: returns false when the shape is not covered (caller falls back to the fp32 kernels)
+bool launch_mha_fwd_x3(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, hipStream_t stream);
+
 }  // namespace hdiff

@@ -1,5 +1,6 @@
 // Error reporting, device query, hipGraph and event helpers of the C ABI (include/hdiff.h).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -11,12 +12,27 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+static int g_contract = -1;
+int contraction_mode() {
+  if (g_contract < 0) {
+    const char* e = getenv("HDIFF_CONTRACT");
+    g_contract = (e && strcmp(e, "bf16x3") == 0) ? HDIFF_CONTRACT_BF16X3 : HDIFF_CONTRACT_F32;
+  }
+  return g_contract;
+}
 }  // namespace hdiff
 
 extern "C" {
 
 int hdiff_abi_version(void) { return 1; }
 const char* hdiff_last_error(void) { return hdiff::g_err; }
+
+int hdiff_set_contraction_mode(int mode) {
+  HDIFF_CHECK_ARG(mode == HDIFF_CONTRACT_F32 || mode == HDIFF_CONTRACT_BF16X3, "set_contraction_mode: unknown mode %d", mode);
+  hdiff::g_contract = mode;
+  return HDIFF_OK;
+}
+int hdiff_get_contraction_mode(void) { return hdiff::contraction_mode(); }
 
 int hdiff_device_count(void) {
   int n = 0;

@@ -175,6 +175,68 @@ def test_flash_attention_fixed_reference_overflow_falls_back():
     close(lse, ref_lse.float(), rel=1e-5, abs_=1e-4, what="lse2")
 
 
+@pytest.fixture
+def bf16x3_mode():
+    lib = _capi.lib()
+    _capi.check(lib.hdiff_set_contraction_mode(1))
+    yield lib
+    _capi.check(lib.hdiff_set_contraction_mode(0))
+
+
+def _flash(lib, qkv, heads, want_lse=False):
+    B, C3, L = qkv.shape
+    Cc = C3 // 3
+    o = torch.empty(B, Cc, L, device=DEV)
+    lse = torch.empty(B, heads, L, device=DEV) if want_lse else None
+    d_qkv = qkv.to(DEV)
+    _capi.check(lib.hdiff_mha_flash_fwd(d_qkv.data_ptr(), o.data_ptr(), lse.data_ptr() if want_lse else None, B, Cc, heads, L,
+                                        torch.cuda.current_stream().cuda_stream), "mha")
+    torch.cuda.synchronize()
+    return o, lse
+
+
+@pytest.mark.parametrize("d,L,B,scale", [(16, 1024, 2, 1.0), (16, 4096, 1, 3.0), (32, 2048, 1, 1.0), (32, 512, 2, 2.0)])
+def test_flash_attention_split_bf16_is_fp32_class(d, L, B, scale, bf16x3_mode):
+    """HDIFF_CONTRACT_BF16X3: fp32 operands as three bf16 pieces, six products on the bf16 MFMA.  Claim checked here: its
+    error against float64 is of the same class as the fp32-MFMA kernel's (not merely inside the tolerance)."""
+    lib = bf16x3_mode
+    g = torch.Generator().manual_seed(100 + d + L)
+    heads = 8
+    qkv = torch.randn(B, 3 * heads * d, L, generator=g) * scale
+    ref = attention_core_ref(qkv, heads).double()
+    o_x3, _ = _flash(lib, qkv, heads)
+    assert lib.hdiff_get_contraction_mode() == 1
+    _capi.check(lib.hdiff_set_contraction_mode(0))
+    o_f32, _ = _flash(lib, qkv, heads)
+    _capi.check(lib.hdiff_set_contraction_mode(1))
+    assert not torch.equal(o_x3, o_f32), "the split-bf16 kernel did not run"
+    close(o_x3, ref.float(), rel=2e-5, abs_=2e-6, what=f"split-bf16 d={d} L={L}")
+    rms = lambda t: (t.double().cpu() - ref).pow(2).mean().sqrt().item()
+    worst = lambda t: (t.double().cpu() - ref).abs().max().item()
+    assert rms(o_x3) <= 1.25 * rms(o_f32) + 1e-12, (rms(o_x3), rms(o_f32))
+    assert worst(o_x3) <= 2.0 * worst(o_f32) + 1e-12, (worst(o_x3), worst(o_f32))
+
+
+def test_flash_attention_split_bf16_overflow_falls_back(bf16x3_mode):
+    """Same fixed-reference protocol as the fp32 fast kernel: spiked keys / queries overflow exp2 on purpose; the poisoned
+    query blocks are recomputed by the overflow-proof kernel."""
+    lib = bf16x3_mode
+    g = torch.Generator().manual_seed(9)
+    heads, d, L, B = 8, 16, 2048, 2
+    Cc = heads * d
+    qkv = torch.randn(B, 3 * Cc, L, generator=g)
+    qkv[0, Cc + 2 * d:Cc + 3 * d, 700] *= 90.0
+    qkv[1, Cc + 5 * d:Cc + 6 * d, 1999] *= 150.0
+    qkv[1, 0 * d:1 * d, 300:364] *= 40.0
+    o, lse = _flash(lib, qkv, heads, want_lse=True)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    close(o, attention_core_ref(qkv, heads), rel=3e-5, abs_=3e-6, what="split-bf16 overflow fallback")
+    q, k, _ = [z.reshape(B, heads, d, L).transpose(2, 3).double() for z in qkv.split(Cc, dim=1)]
+    s2 = (q @ k.transpose(2, 3)) / math.sqrt(d) * math.log2(math.e)
+    ref_lse = torch.logsumexp(s2 * math.log(2.0), dim=-1) / math.log(2.0)
+    close(lse, ref_lse.float(), rel=1e-5, abs_=1e-4, what="lse2 (split-bf16)")
+
+
 def test_linear_rows_and_gather():
     g = torch.Generator().manual_seed(1)
     table = torch.randn(20, 128, generator=g)

@@ -46,6 +46,23 @@ def test_argument_validation_without_gpu():
     assert lib.hdiff_conv2d_fwd(d, None) == -1
 
 
+def test_contraction_mode_switch():
+    """hdiff_set_contraction_mode is process-wide, validated, and readable back (no launch is made here)."""
+    lib = hdiff_amd.lib()
+    start = lib.hdiff_get_contraction_mode()
+    assert start in (0, 1)
+    try:
+        assert lib.hdiff_set_contraction_mode(1) == 0 and lib.hdiff_get_contraction_mode() == 1
+        assert lib.hdiff_set_contraction_mode(7) == -1 and b"unknown mode" in lib.hdiff_last_error()
+        assert lib.hdiff_get_contraction_mode() == 1
+        hdiff_amd.set_contraction_mode("f32")
+        assert hdiff_amd.get_contraction_mode() == "f32"
+        with pytest.raises(ValueError):
+            hdiff_amd.set_contraction_mode("fp8")
+    finally:
+        lib.hdiff_set_contraction_mode(start)
+
+
 def test_product_path_refuses_cpu_tensors():
     m = MC.UNet(T=8, num_labels=3, ch=32, ch_mult=[1, 2], num_res_blocks=1, dropout=0.0).eval()
     x, t, lab = torch.zeros(1, 3, 16, 16), torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.long)

@@ -1,0 +1,53 @@
+"""Dev tool: accuracy (vs float64) and speed of the split-bf16 attention forward against the fp32-MFMA kernels."""
+import math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch, hdiff_amd
+lib = hdiff_amd.lib()
+s = torch.cuda.current_stream().cuda_stream
+
+
+def ref64(qkv, heads):
+    B, C3, L = qkv.shape
+    Cc = C3 // 3
+    d = Cc // heads
+    q, k, v = [z.reshape(B, heads, d, L).transpose(2, 3).double() for z in qkv.split(Cc, dim=1)]
+    w = torch.softmax(q @ k.transpose(2, 3) / math.sqrt(d), dim=-1)
+    return (w @ v).transpose(2, 3).reshape(B, Cc, L)
+
+
+def run(mode, qkv, heads):
+    B, C3, L = qkv.shape
+    lib.hdiff_set_contraction_mode(mode)
+    o = torch.empty(B, C3 // 3, L, device="cuda")
+    rc = lib.hdiff_mha_flash_fwd(qkv.data_ptr(), o.data_ptr(), None, B, C3 // 3, heads, L, s)
+    assert rc == 0, lib.hdiff_last_error()
+    torch.cuda.synchronize()
+    return o
+
+
+for d, L, scale in [(16, 2048, 1.0), (16, 4096, 3.0), (32, 2048, 1.0), (32, 1024, 2.0)]:
+    g = torch.Generator().manual_seed(d + L)
+    qkv = (torch.randn(1, 3 * 8 * d, L, generator=g) * scale).cuda()
+    r = ref64(qkv, 8)
+    for mode, name in [(0, "f32   "), (1, "bf16x3")]:
+        o = run(mode, qkv, 8).double()
+        err = (o - r).abs()
+        print(f"d={d} L={L} scale={scale} {name}: max abs err {err.max().item():.3e}  rms err {err.pow(2).mean().sqrt().item():.3e}"
+              f"  (rms of ref {r.pow(2).mean().sqrt().item():.3e})", flush=True)
+
+if len(sys.argv) > 1 and sys.argv[1] == "time":
+    for (B, Cc, L) in [(1, 128, 65536), (2, 256, 16384), (4, 256, 4096)]:
+        qkv = torch.randn(B, 3 * Cc, L, device="cuda")
+        o = torch.empty(B, Cc, L, device="cuda")
+        for mode, name in [(0, "f32   "), (1, "bf16x3")]:
+            lib.hdiff_set_contraction_mode(mode)
+            for _ in range(2):
+                lib.hdiff_mha_flash_fwd(qkv.data_ptr(), o.data_ptr(), None, B, Cc, 8, L, s)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                lib.hdiff_mha_flash_fwd(qkv.data_ptr(), o.data_ptr(), None, B, Cc, 8, L, s)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            print(f"{name} B={B} C={Cc} L={L}: {ms:.3f} ms  {4.0 * L * L * Cc * B / ms / 1e9:.1f} TFLOP/s (fp32-equivalent)", flush=True)
