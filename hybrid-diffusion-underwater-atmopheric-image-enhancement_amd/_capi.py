@@ -84,6 +84,11 @@ _PROTOS = {
                                   C.c_void_p, C.c_void_p, C.c_double, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p]),
     "hdiff_fill_t": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "hdiff_step_decrement": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hdiff_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hdiff_fill_from_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "hdiff_resize_nearest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hdiff_avgpool_global": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "hdiff_concat2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "hdiff_clip": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_void_p]),
     "hdiff_axpby": (C.c_int, [C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hdiff_randn": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),

@@ -437,3 +437,133 @@ class UNetPlan:
         self.out = plan.buf(B, 3, H, W)
         plan.conv(h, None, pk_tail, P["tail.2.bias"], self.out, B=B, H=H, W=W, VH=H, VW=W, gn=sct)
         plan.keep((temb, cemb, h))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# DynamicUNet emitter (the reference's second tree: diffusion/Model.py:382-517)
+# ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class DynUNetShape:
+    T: int
+    ch: int
+    ch_mult: Tuple[int, ...]
+    num_res_blocks: int
+
+
+def emit_cond_image_embedding(plan: Plan, P: Dict[str, torch.Tensor], p: str, img: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    """ConditionalEmbedding.forward (diffusion/Model.py:135-166): three stride-2 3x3 convs with no activation in between,
+    global average pool, Linear -> Swish -> Linear."""
+    x, cH, cW = img, H, W
+    for name in ("conv1", "conv2", "conv3"):
+        w = P[f"{p}.{name}.weight"]
+        pk = _std_pack(plan, w, 3, 1)
+        oH, oW = (cH - 1) // 2 + 1, (cW - 1) // 2 + 1
+        y = plan.buf(B, int(w.shape[0]), oH, oW)
+        plan.conv(x, None, pk, P[f"{p}.{name}.bias"], y, B=B, H=cH, W=cW, VH=oH, VW=oW, in_stride=2)
+        if x is not img:
+            plan.free(x)
+        x, cH, cW = y, oH, oW
+    Cc = int(x.shape[1])
+    pooled = plan.buf(B, Cc)
+    plan.call("hdiff_avgpool_global", x.data_ptr(), pooled.data_ptr(), B * Cc, cH * cW)
+    plan.keep((x, pooled))
+    plan.free(x)
+    w1, w2 = P[f"{p}.linear1.weight"], P[f"{p}.linear2.weight"]
+    h = plan.buf(B, int(w1.shape[0]))
+    out = plan.buf(B, int(w2.shape[0]))
+    plan.linear(pooled, None, w1, P[f"{p}.linear1.bias"], h, B, swish_input=False, accumulate=False)
+    plan.linear(h, None, w2, P[f"{p}.linear2.bias"], out, B, swish_input=True, accumulate=False)
+    plan.free(pooled); plan.free(h)
+    return out
+
+
+class DynUNetPlan:
+    """Launch plan of one DynamicUNet.forward (diffusion/Model.py:475-515) for a fixed (B, H, W).
+
+    The inputs are two 3-channel tensors (``cond`` = the conditioning image, ``y`` = the noisy image, which the sampler
+    updates in place); their ``torch.cat`` (Diffusion.py:229,252) is one small launch into ``x6`` -- 3 channels are too
+    narrow for the conv's 4-channel-aligned two-pointer input.  ``context_zero`` selects a zero conditional embedding
+    (what the reference's sampler always uses) or the conv embedding of ``label`` (an image)."""
+
+    def __init__(self, P: Dict[str, torch.Tensor], shape: DynUNetShape, B: int, H: int, W: int, device, context_zero: bool,
+                 taps: Optional[Dict[str, torch.Tensor]] = None):
+        plan = Plan(device)
+        if taps is not None:               # test hook: keep every block output alive (no buffer reuse) and name it
+            plan.free = lambda t: None     # type: ignore[method-assign]
+        else:
+            taps = {}
+        self.plan, self.B, self.H, self.W = plan, B, H, W
+        self.cond = plan.buf(B, 3, H, W)
+        self.y = plan.buf(B, 3, H, W)
+        self.t = plan.buf(B, dtype=torch.int64)
+        self.label = None if context_zero else plan.buf(B, 3, H, W)
+        ch = shape.ch
+        temb = emit_embed_mlp(plan, P, "time_embedding.timembedding", self.t, B)
+        if context_zero:
+            # torch.zeros_like(temb), Model.py:482-483.  Its own allocation, NOT a pooled buffer: it is written once here, and a
+            # pooled buffer would be the recycled scratch of the time MLP, rewritten on every run
+            cemb = torch.zeros(B, 4 * ch, dtype=torch.float32, device=plan.device)
+            self._zero = cemb
+        else:
+            cemb = emit_cond_image_embedding(plan, P, "cond_embedding", self.label, B, H, W)
+            self._zero = None
+
+        self.x6 = plan.buf(B, 6, H, W)
+        plan.call("hdiff_concat2", self.cond.data_ptr(), self.y.data_ptr(), self.x6.data_ptr(), B, 3 * H * W, 3 * H * W)
+        pk_head = _std_pack(plan, P["head.weight"], 3, 1)
+        h = plan.buf(B, ch, H, W)
+        plan.conv(self.x6, None, pk_head, P["head.bias"], h, B=B, H=H, W=W, VH=H, VW=W)
+        taps["temb"], taps["cemb"], taps["head"] = temb, cemb, h
+        hs: List[Tuple[torch.Tensor, int, int, int]] = [(h, ch, H, W)]
+        now, cH, cW = ch, H, W
+        n = 0
+        for i, mult in enumerate(shape.ch_mult):
+            for _ in range(shape.num_res_blocks):
+                h = emit_resblock(plan, P, f"downblocks.{n}", h, None, temb, cemb, ch * mult, B, cH, cW, attn=False)
+                taps[f"downblocks.{n}"] = h
+                n += 1
+                now = ch * mult
+                hs.append((h, now, cH, cW))
+            if i != len(shape.ch_mult) - 1:
+                h = emit_downsample(plan, P, f"downblocks.{n}", h, B, now, cH, cW)
+                taps[f"downblocks.{n}"] = h
+                n += 1
+                cH, cW = (cH - 1) // 2 + 1, (cW - 1) // 2 + 1
+                hs.append((h, now, cH, cW))
+        owned = False                      # the last down output is also a skip tensor: it must outlive the middle
+        for k in range(4):                 # four attention ResBlocks (Model.py:425-431)
+            y = emit_resblock(plan, P, f"middleblocks.{k}", h, None, temb, cemb, now, B, cH, cW, attn=True)
+            if owned:
+                plan.free(h)
+            h, owned = y, True
+            taps[f"middleblocks.{k}"] = h
+        n = 0
+        for i, mult in reversed(list(enumerate(shape.ch_mult))):
+            for _ in range(shape.num_res_blocks):
+                skip, sc, sH, sW = hs.pop()
+                if (sH, sW) != (cH, cW):   # F.interpolate(skip, size=h.shape[2:], mode="nearest"), Model.py:503-504
+                    r = plan.buf(B, sc, cH, cW)
+                    plan.call("hdiff_resize_nearest", skip.data_ptr(), r.data_ptr(), B * sc, sH, sW, cH, cW)
+                    plan.keep((skip, r))
+                    plan.free(skip)
+                    skip = r
+                y = emit_resblock(plan, P, f"upblocks.{n}", h, skip, temb, cemb, ch * mult, B, cH, cW, attn=False)
+                taps[f"upblocks.{n}"] = y
+                n += 1
+                plan.free(h); plan.free(skip)
+                h, now = y, ch * mult
+            if i != 0:
+                y = emit_upsample(plan, P, f"upblocks.{n}", h, B, now, cH, cW)
+                taps[f"upblocks.{n}"] = y
+                n += 1
+                plan.free(h)
+                h, cH, cW = y, 2 * cH, 2 * cW
+        for skip, _, _, _ in hs:           # skips the reference never consumes
+            plan.free(skip)
+        sct = plan.gn_scale_shift(h, None, P["tail.0.weight"], P["tail.0.bias"], B, cH * cW)
+        pk_tail = _std_pack(plan, P["tail.2.weight"], 3, 1)
+        self.out_hw = (cH, cW)
+        self.out = plan.buf(B, 3, cH, cW)
+        plan.conv(h, None, pk_tail, P["tail.2.bias"], self.out, B=B, H=cH, W=cW, VH=cH, VW=cW, gn=sct)
+        self.tail_in_src = (h, sct)        # kept for tests: the tensor entering the tail and its GN scale/shift
+        plan.keep((temb, cemb, h))

@@ -198,6 +198,24 @@ int hdiff_ddpm_step(const float* x, const float* eps_c, const float* eps_u, cons
 /* step bookkeeping for the captured loop: t[b] = *step for all b (int64 vector for the embedding gather) */
 int hdiff_fill_t(int64_t* t, const int32_t* step_ptr, int B, hdiff_stream_t stream);
 int hdiff_step_decrement(int32_t* step_ptr, hdiff_stream_t stream);
+/* ------------------------------------------------------------------------------------------------------------------
+ * Image-conditioned sampler of the reference's second tree (diffusion/Diffusion.py:182-269, diffusion/Model.py).
+ *   hdiff_ddim_step        one deterministic DDIM update (Diffusion.py:259-263, eta = 0):
+ *                          y0 = (y - eps*tab[k][0]) / tab[k][1] ; y_next = tab[k][2]*y0 + tab[k][3]*eps, k = *step_ptr;
+ *                          tab[k] = {sqrt(1-at), sqrt(at), sqrt(at_next), sqrt(1-at_next)} in fp32 (host builds it with the
+ *                          reference's own tensor ops); nan_flag is OR-ed with 1 on a NaN output
+ *   hdiff_fill_from_table  dst[i] = table[*idx] for i < n: the DDIM time-step vector t of step k (Diffusion.py:249)
+ *   hdiff_resize_nearest   F.interpolate(mode="nearest") of [BC][H][W] to [BC][OH][OW] (skip tensors, Model.py:503-504)
+ *   hdiff_avgpool_global   nn.AdaptiveAvgPool2d((1,1)) of [BC][HW] -> [BC] (ConditionalEmbedding, Model.py:124,150)
+ *   hdiff_concat2          out[b] = [a[b] (n0 floats) | b[b] (n1 floats)]: torch.cat([input_image, y_t], dim=1) of
+ *                          Diffusion.py:229,252 (3 + 3 channels: too narrow for the conv's two-pointer input)
+ * ------------------------------------------------------------------------------------------------------------------ */
+int hdiff_ddim_step(const float* y, const float* eps, float* y_next, const float* tab, const int32_t* step_ptr,
+                    int32_t* nan_flag, int64_t n, hdiff_stream_t stream);
+int hdiff_fill_from_table(int64_t* dst, const int32_t* table, const int32_t* idx, int n, hdiff_stream_t stream);
+int hdiff_resize_nearest(const float* x, float* y, int BC, int H, int W, int OH, int OW, hdiff_stream_t stream);
+int hdiff_avgpool_global(const float* x, float* y, int BC, int HW, hdiff_stream_t stream);
+int hdiff_concat2(const float* a, const float* b, float* out, int B, int64_t n0, int64_t n1, hdiff_stream_t stream);
 /* final clip (:98) */
 int hdiff_clip(const float* x, float* y, float lo, float hi, int64_t n, hdiff_stream_t stream);
 /* out = a*x + b*y (y may be NULL): bias merges and other weight-preparation arithmetic */

@@ -1,0 +1,34 @@
+"""Dev tool: per-block comparison of the DynamicUNet launch plan against the CPU oracle (small golden model)."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import hdiff_amd
+from hdiff_amd import engine as E
+from hdiff_amd.diffusion.Model import DynamicUNet
+from hdiff_amd.DiffusionFreeGuidence.ModelCondition import _params_of
+from oracle import cpu_path_b as OB
+
+d = np.load(os.path.join(ROOT, "tests/golden/dyn_unet_small.npz"))
+cfg = json.loads(bytes(d["cfg_json"]).decode())
+m = DynamicUNet(**cfg).eval()
+sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd/")}
+m.load_state_dict(sd)
+m = m.to("cuda:0")
+ocfg = OB.DynUNetConfig(T=cfg["T"], ch=cfg["ch"], ch_mult=tuple(cfg["ch_mult"]), num_res_blocks=cfg["num_res_blocks"])
+tag = sys.argv[1] if len(sys.argv) > 1 else "s16"
+x, t = torch.from_numpy(d[f"{tag}/x"]), torch.from_numpy(d[f"{tag}/t"])
+otaps = {}
+with torch.no_grad():
+    want = OB.dyn_unet_forward(sd, ocfg, x, t, taps=otaps)
+    taps = {}
+    B, _, H, W = x.shape
+    up = E.DynUNetPlan(_params_of(m), m._shape, B, H, W, "cuda:0", True, taps=taps)
+    up.plan.pack_weights()
+    up.cond.copy_(x[:, :3]); up.y.copy_(x[:, 3:]); up.t.copy_(t)
+    up.plan.run()
+    torch.cuda.synchronize()
+    for k, v in taps.items():
+        if k in otaps:
+            o = otaps[k]
+            print(f"{k:16s} shape {tuple(v.shape)} max|ref| {o.abs().max():.3e}  max err {(v.cpu() - o).abs().max():.3e}")
+    print("out", (up.out.cpu() - want).abs().max().item())
