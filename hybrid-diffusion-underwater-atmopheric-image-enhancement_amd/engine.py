@@ -123,6 +123,7 @@ class Plan:
         self._keep: List[object] = []
         self.graph = C.c_void_p(None)
         self._graph_stream: Optional[torch.cuda.Stream] = None
+        self.flops = 0.0          # algorithmic FLOPs of the MFMA-bound launches (convolutions, attention) of one run
 
     # -- memory -------------------------------------------------------------------------------------------------------
     def buf(self, *shape: int, dtype=torch.float32) -> torch.Tensor:
@@ -221,6 +222,7 @@ class Plan:
             ws = self.buf(need.value)
             d.splitk_ws, d.splitk_floats = ws.data_ptr(), need.value
         self.keep((d, x0, x1, pk, bias, out, gn, addvec, residual, ws))
+        self.flops += 2.0 * pk.ntaps * pk.cin * pk.cout * VH * VW * B
         self.call("hdiff_conv2d_fwd", C.byref(d))
         if ws is not None:
             self.free(ws)
@@ -299,6 +301,7 @@ def emit_mha(plan: Plan, P: Dict[str, torch.Tensor], p: str, h: torch.Tensor, B:
     plan.conv(h, None, pk_in, P[f"{p}.attn.in_proj_bias"], qkv, B=B, H=H, W=W, VH=H, VW=W)
     o = plan.buf(B, Cc, H, W)
     plan.call("hdiff_mha_flash_fwd", qkv.data_ptr(), o.data_ptr(), None, B, Cc, NUM_HEADS, H * W)
+    plan.flops += 4.0 * (H * W) ** 2 * Cc * B
     plan.keep((qkv, o))
     plan.free(qkv)
     y = plan.buf(B, Cc, H, W)

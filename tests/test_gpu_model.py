@@ -114,6 +114,9 @@ def test_unet_default64_golden_seeded_weights():
             e = maxerr(y, T(d[f"eps_label{lab}"]))
             print(f"unet_default64 label={lab} max err {e:.3e}")
             assert e < 2e-4, (lab, e)
+    # the plan's own FLOP count (convolutions + attention) against SURVEY.md section 8a: 74.0 GFLOP per sample-forward at 64x64
+    flops = m.plan_for(1, 64, 64, torch.device(DEV)).plan.flops
+    assert abs(flops / 74.0e9 - 1.0) < 0.01, flops
 
 
 def test_sampler_small_teacher_forced_and_graph():
