@@ -53,7 +53,11 @@ __device__ __forceinline__ float swish_fast(float v) { return v * __builtin_amdg
 // SPEC = 1: the 3x3 / stride-1 / 8x32-pixel-tile case (every heavy conv of the U-Net).  Patch geometry is then a
 // compile-time constant (row stride 35, plane 350), the (tap, k-pair) loop is fully unrolled and every LDS operand address
 // is base register + immediate: no VALU instruction is issued between the MFMAs (each one would cost MFMA issue time).
-template <int WN, int CK, int NXS, int NWS, int SPEC>
+// TWOM: both 32-channel M tiles are computed (any launch with Cout > 32).  The packed weights are zero padded to 64-channel
+// blocks, so the second tile is always safe to compute and rows >= Cout are simply not stored; keeping this a template
+// parameter (not a runtime test) matters: a branch inside the unrolled MFMA loop stops the compiler from hoisting the LDS
+// operand reads across k-steps (it does not change the measured rate: the kernel is not bound by those reads).
+template <int WN, int CK, int NXS, int NWS, int SPEC, bool TWOM>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sX = smem;                       // [CK][PLANE]
@@ -78,13 +82,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   int x_soff[NXS];     // ci*H*W + iy*W + ix inside the chunk's first plane, or -1 when the position is zero padding
   int x_meta[NXS];     // LDS float offset | ci << 24
   {
-    const int plane_elems = p.PH * p.PW;
+    // SPEC: the patch is (8 + 2) x (32 + 2) -- divisions by compile-time constants
+    const int plane_elems = SPEC ? 340 : p.PH * p.PW;
+    const int pw = SPEC ? 34 : p.PW;
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
       const int e = tid + i * NTHREADS;
       const int ci = e / plane_elems;
       const int rem = e - ci * plane_elems;
-      const int py = rem / p.PW, px = rem - py * p.PW;
+      const int py = rem / pw, px = rem - py * pw;
       const int iy = iy0 + py, ix = ix0 + px;
       const bool in_slot = (i < p.nx) && (ci < CK);
       const bool in_img = in_slot && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const bool two_m = (p.Cout - co0) > 32;
+  constexpr bool two_m = TWOM;
 
   float xr[NXS];
   float4 wr[NWS];
@@ -307,20 +313,26 @@ int ceil_log2(int v) {
   return l;
 }
 
-template <int WN, int CK, int NXS, int NWS, int SPEC>
-int launch(const ConvK& k, int B, size_t lds_bytes, hipStream_t stream) {
+template <int WN, int CK, int NXS, int NWS, int SPEC, bool TWOM>
+void launch_t(const ConvK& k, dim3 grid, size_t lds_bytes, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WN, CK, NXS, NWS, SPEC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WN, CK, NXS, NWS, SPEC, TWOM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  hipLaunchKernelGGL((conv_igemm_kernel<WN, CK, NXS, NWS, SPEC, TWOM>), grid, dim3(NTHREADS), lds_bytes, stream, k);
+}
+
+template <int WN, int CK, int NXS, int NWS, int SPEC>
+int launch(const ConvK& k, int B, size_t lds_bytes, hipStream_t stream) {
   const int BN = 128 * WN;
   const int TW = 1 << k.tw_log2;
   const int tiles_y = cdiv(k.VH, BN / TW);
   dim3 grid(k.tiles_x * tiles_y, cdiv(k.Cout, BM), B * k.ksplit);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  hipLaunchKernelGGL((conv_igemm_kernel<WN, CK, NXS, NWS, SPEC>), grid, dim3(NTHREADS), lds_bytes, stream, k);
+  if (k.Cout > 32) launch_t<WN, CK, NXS, NWS, SPEC, true>(k, grid, lds_bytes, stream);
+  else launch_t<WN, CK, NXS, NWS, SPEC, false>(k, grid, lds_bytes, stream);
   if (k.ksplit > 1) {
     const size_t n = (size_t)B * k.Cout * k.VH * k.VW;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
