@@ -65,6 +65,25 @@ def test_conv1x1_and_5x5_stride2():
     close(run_conv(x, None, w3, None, 3, 1, stride=2), F.conv2d(x, w3, None, stride=2, padding=1), what="conv3x3s2")
 
 
+@pytest.mark.parametrize("C0,C1,cout", [(64, 0, 128), (64, 31, 96), (128, 128, 40), (256, 0, 768)])
+def test_conv1x1_direct_gemm_path(C0, C1, cout):
+    """Full-resolution 1x1 convs (B*H*W >= 32768, H*W % 128 == 0) take the LDS-free GEMM kernel (conv1x1_direct.hip):
+    two-pointer concat input, odd channel counts, channel tails, bias + per-sample vector + residual epilogue."""
+    g = torch.Generator().manual_seed(C0 + C1 + cout)
+    B, H, W = 2, 128, 128
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    cin = C0 + C1
+    w = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    vec = torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g)
+    xin = x0 if x1 is None else torch.cat([x0, x1], dim=1)
+    want = F.conv2d(xin.double(), w.double(), b.double()) + vec.double()[:, :, None, None] + res.double()
+    close(run_conv(x0, x1, w, b, 1, 0, addvec=vec, residual=res), want.float(), rel=1e-5, what="conv1x1 direct")
+    close(run_conv(x0, x1, w, None, 1, 0), F.conv2d(xin.double(), w.double()).float(), rel=1e-5, what="conv1x1 direct, no epilogue")
+
+
 def test_conv_fused_prologue_epilogue_concat():
     g = torch.Generator().manual_seed(9)
     B, C0, C1, Cout, H, W = 2, 64, 32, 64, 16, 16
