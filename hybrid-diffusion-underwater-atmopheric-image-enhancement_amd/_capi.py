@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
         ("VH", C.c_int), ("VW", C.c_int), ("in_stride", C.c_int),
         ("out_sy", C.c_int), ("out_oy", C.c_int), ("out_sx", C.c_int), ("out_ox", C.c_int),
         ("ntaps", C.c_int), ("tap_dy", C.c_int * MAX_TAPS), ("tap_dx", C.c_int * MAX_TAPS),
-        ("splitk_ws", C.c_void_p), ("splitk_floats", C.c_int64),
+        ("splitk_ws", C.c_void_p), ("splitk_floats", C.c_int64), ("wp_x3", C.c_void_p),
     ]
 
 
@@ -47,6 +47,7 @@ _PROTOS = {
     "hdiff_abi_version": (C.c_int, []),
     "hdiff_last_error": (C.c_char_p, []),
     "hdiff_device_count": (C.c_int, []),
+    "hdiff_pack_conv_weight_x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hdiff_set_contraction_mode": (C.c_int, [C.c_int]),
     "hdiff_get_contraction_mode": (C.c_int, []),
     "hdiff_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

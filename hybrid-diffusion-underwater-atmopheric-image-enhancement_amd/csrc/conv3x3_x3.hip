@@ -1,0 +1,269 @@
+// 3x3 / stride-1 convolution with fp32 operands carried as three bf16 pieces on the bf16 matrix core
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulation) -- the HDIFF_CONTRACT_BF16X3 counterpart of conv_igemm.hip's fast path
+// (reference call sites: ModelCondition.py:172, 186, 88 / diffusion/Model.py:275, 288, 184).
+//
+// Arithmetic: x = x0 + x1 + x2 exactly (top-16-bit truncations of successive exact remainders, attention_x3.hip), and
+// w * x = sum over the six piece pairs with i + j <= 2 (dropped terms <= 3 * 2^-24 relative): fp32-class, checked against
+// float64 next to the fp32-MFMA kernel in tests/test_gpu_ops.py.  Why it pays more here than in attention: both operands
+// are split ONCE per staged element (the weights even once per model, by hdiff_pack_conv_weight_x3) and then used by 9 taps
+// x 64 channels, so the split is noise and the kernel gets the 6/16 matrix-time ratio.
+//
+// Structure per workgroup (64 output channels x 8x32 pixels, 4 waves x 64 pixels), per chunk of 16 input channels:
+//   * the (8+2) x (32+2) activation patch: global -> registers (prefetched one chunk ahead) -> GroupNorm affine + Swish ->
+//     three bf16 pieces -> LDS as [piece][pixel][16 channels]: a lane's B operand (8 consecutive channels of one pixel) is one
+//     16-byte LDS read, and a tap is just a pixel offset;
+//   * the weights are not staged: hdiff_pack_conv_weight_x3 lays them out as [chunk][tap][piece][channel][16 ci], so a lane's
+//     A operand is one 16-byte global load (L1/L2 resident: every workgroup of the launch reads the same 55 KB per chunk);
+//   * per tap 6 piece pairs x (2 x 2) tiles = 24 MFMAs; the next tap's weight loads are issued before them.
+#include "common.h"
+
+using namespace hdiff;
+
+namespace hdiff {
+struct ConvX3K {
+  const float* x0;
+  const float* x1;
+  int C0, C1, Cin, H, W;
+  const unsigned* wp3;             // [Cin/16][9][3][CoutPad][8] packed bf16 pairs
+  int CoutPad, Cout;
+  const float* bias;
+  const float* gn_scale;
+  const float* gn_shift;
+  const float* addvec;
+  const float* residual;
+  float* out;
+  int tiles_x;
+};
+}  // namespace hdiff
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int PH = 10, PW = 34, PPIX = PH * PW;      // patch of an 8 x 32 tile
+constexpr int NSLOT = (8 * PPIX + THREADS - 1) / THREADS;   // (channel pair, pixel) staging slots per thread: 11
+constexpr int PIECE_WORDS = PPIX * 8;                 // 32-bit words of one piece plane: [pixel][8 channel pairs]
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float swish_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+}
+__device__ __forceinline__ float top16(float x) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u);
+}
+// (a, b) -> three packed bf16 pairs, a = a0 + a1 + a2 exactly (plain VALU only: see attention_x3.hip)
+__device__ __forceinline__ void split3(float a, float b, unsigned& h0, unsigned& h1, unsigned& h2) {
+  h0 = pack_hi16(a, b);
+  const float ra = a - top16(a), rb = b - top16(b);
+  h1 = pack_hi16(ra, rb);
+  const float sa = ra - top16(ra), sb = rb - top16(rb);
+  h2 = pack_hi16(sa, sb);
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// split-product terms kept (piece of W, piece of X): all i + j <= 2, small ones first
+__device__ constexpr int TERM_W[6] = {2, 1, 0, 1, 0, 0};
+__device__ constexpr int TERM_X[6] = {0, 1, 2, 0, 1, 0};
+
+__global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
+  __shared__ __attribute__((aligned(16))) unsigned sX[3 * PIECE_WORDS];
+  extern __shared__ __attribute__((aligned(16))) float sG[];     // [2][Cin]: GroupNorm scale | shift of this sample
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z;
+  const int co0 = blockIdx.y * 64;
+  const int tile_y = blockIdx.x / p.tiles_x, tile_x = blockIdx.x - tile_y * p.tiles_x;
+  const int vy0 = tile_y * 8, vx0 = tile_x * 32;
+  const bool has_gn = p.gn_scale != nullptr;
+  const size_t HW = (size_t)p.H * p.W;
+
+  // staging slots: slot e = (channel pair j = e / 340, patch pixel e % 340)
+  int s_goff[NSLOT];      // iy * W + ix of the pixel, or -1 (zero padding / unused slot)
+  int s_lds[NSLOT];       // word offset inside a piece plane, or -1 (unused slot)
+  int s_pair[NSLOT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int e = tid + i * THREADS;
+    const int j = e / PPIX, pos = e - j * PPIX;
+    const int py = pos / PW, px = pos - py * PW;
+    const int iy = vy0 - 1 + py, ix = vx0 - 1 + px;
+    const bool used = j < 8;
+    s_pair[i] = j;
+    s_lds[i] = used ? pos * 8 + j : -1;
+    s_goff[i] = (used && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
+  }
+  if (has_gn) {
+    for (int i = tid; i < 2 * p.Cin; i += THREADS)
+      sG[i] = (i < p.Cin) ? p.gn_scale[b * p.Cin + i] : p.gn_shift[b * p.Cin + (i - p.Cin)];
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  float xa[NSLOT], xb[NSLOT];
+  auto issue_loads = [&](int c0) {
+    // a 16-channel chunk never straddles the concat seam (C0 % 16 == 0 is checked on the host)
+    const float* xbase = (c0 < p.C0) ? p.x0 + ((size_t)b * p.C0 + c0) * HW : p.x1 + ((size_t)b * p.C1 + (c0 - p.C0)) * HW;
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const bool ok = s_goff[i] >= 0;
+      const float* src = xbase + (size_t)(2 * s_pair[i]) * HW + (ok ? s_goff[i] : 0);
+      xa[i] = ok ? src[0] : 0.f;
+      xb[i] = ok ? src[HW] : 0.f;
+    }
+  };
+  auto store_staged = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      if (s_lds[i] >= 0) {
+        float a = xa[i], c = xb[i];
+        if (has_gn && s_goff[i] >= 0) {
+          const int ci = c0 + 2 * s_pair[i];
+          a = swish_fast(fmaf(a, sG[ci], sG[p.Cin + ci]));
+          c = swish_fast(fmaf(c, sG[ci + 1], sG[p.Cin + ci + 1]));
+        }
+        unsigned h0, h1, h2;
+        split3(a, c, h0, h1, h2);
+        sX[s_lds[i]] = h0;
+        sX[PIECE_WORDS + s_lds[i]] = h1;
+        sX[2 * PIECE_WORDS + s_lds[i]] = h2;
+      }
+    }
+  };
+
+  // operand addresses: B = 8 channels (h picks the half) of pixel (row, l31) of this wave's N tile; A = 8 input channels of
+  // output channel co0 + mt*32 + l31
+  int boff[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) boff[nt] = ((wave * 2 + nt) * PW + l31) * 8 + h * 4;
+  const unsigned* wlane = p.wp3 + ((size_t)(co0 + l31) * 8 + h * 4);
+  const size_t w_piece = (size_t)p.CoutPad * 8;            // words between pieces
+  const size_t w_tap = 3 * w_piece, w_chunk = 9 * w_tap;
+
+  auto load_w = [&](u32x4 (&wa)[2][3], int chunk, int tap) {
+    const unsigned* wb = wlane + (size_t)chunk * w_chunk + (size_t)tap * w_tap;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) wa[mt][pc] = *reinterpret_cast<const u32x4*>(wb + pc * w_piece + mt * 32 * 8);
+  };
+  auto mma_tap = [&](const u32x4 (&wa)[2][3], int tap) {
+    const int toff = ((tap / 3) * PW + (tap % 3)) * 8;
+    u32x4 xp[2][3];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) xp[nt][pc] = *reinterpret_cast<const u32x4*>(&sX[pc * PIECE_WORDS + boff[nt] + toff]);
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(wa[mt][TERM_W[t]], xp[nt][TERM_X[t]], acc[mt][nt]);
+  };
+
+  const int nchunks = p.Cin / 16;
+  issue_loads(0);
+  __syncthreads();     // sG visible
+  for (int c = 0; c < nchunks; ++c) {
+    store_staged(c * 16);
+    __syncthreads();
+    if (c + 1 < nchunks) issue_loads((c + 1) * 16);
+    u32x4 wA[2][3], wB[2][3];
+    load_w(wA, c, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; tap += 2) {
+      if (tap + 1 < 9) load_w(wB, c, tap + 1);
+      mma_tap(wA, tap);
+      if (tap + 2 < 9) load_w(wA, c, tap + 2);
+      if (tap + 1 < 9) mma_tap(wB, tap + 1);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: + bias + per-sample channel vector + residual, NCHW store (32 consecutive pixels per register row)
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int vy = vy0 + wave * 2 + nt, vx = vx0 + l31;
+    if (vy >= p.H || vx >= p.W) continue;
+    const size_t pix = (size_t)vy * p.W + vx;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < p.Cout) {
+          float v = acc[mt][nt][r];
+          if (p.bias) v += p.bias[co];
+          if (p.addvec) v += p.addvec[b * p.Cout + co];
+          const size_t o = ((size_t)b * p.Cout + co) * HW + pix;
+          if (p.residual) v += p.residual[o];
+          p.out[o] = v;
+        }
+      }
+  }
+}
+
+// fp32 [Cout][Cin][3][3] -> [Cin/16][tap][piece][CoutPad][8 words]: word j of a row = bf16 pieces of input channels 2j, 2j+1
+__global__ void pack_conv_weight_x3_kernel(const float* __restrict__ w, unsigned* __restrict__ wp3, int Cout, int Cin,
+                                           int CoutPad) {
+  const size_t n = (size_t)(Cin / 16) * 9 * CoutPad * 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % 8);
+    size_t r = i / 8;
+    const int co = (int)(r % CoutPad);
+    r /= CoutPad;
+    const int tap = (int)(r % 9);
+    const int chunk = (int)(r / 9);
+    float a = 0.f, c = 0.f;
+    if (co < Cout) {
+      const int ci = chunk * 16 + 2 * j;
+      a = w[((size_t)co * Cin + ci) * 9 + tap];
+      c = w[((size_t)co * Cin + ci + 1) * 9 + tap];
+    }
+    unsigned h0, h1, h2;
+    split3(a, c, h0, h1, h2);
+    const size_t base = ((size_t)(chunk * 9 + tap) * 3) * CoutPad * 8 + (size_t)co * 8 + j;
+    wp3[base] = h0;
+    wp3[base + (size_t)CoutPad * 8] = h1;
+    wp3[base + 2 * (size_t)CoutPad * 8] = h2;
+  }
+}
+
+}  // namespace
+
+namespace hdiff {
+
+void launch_conv3x3_x3(const ConvX3K& k, int B, hipStream_t stream) {
+  const int tiles_y = cdiv(k.H, 8);
+  dim3 grid(k.tiles_x * tiles_y, cdiv(k.Cout, 64), B);
+  const size_t dyn = (size_t)2 * k.Cin * sizeof(float);
+  hipLaunchKernelGGL(conv3x3_x3_kernel, grid, dim3(THREADS), dyn, stream, k);
+}
+
+}  // namespace hdiff
+
+extern "C" int hdiff_pack_conv_weight_x3(const float* w, void* wp3, int Cout, int Cin, int CoutPad, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(w && wp3, "pack_conv_weight_x3: null pointer");
+  HDIFF_CHECK_ARG(Cout > 0 && Cin > 0 && Cin % 16 == 0 && CoutPad >= Cout && CoutPad % 64 == 0,
+                  "pack_conv_weight_x3: needs Cin %% 16 == 0 and CoutPad %% 64 == 0 (Cin %d, Cout %d, CoutPad %d)", Cin, Cout, CoutPad);
+  const size_t n = (size_t)(Cin / 16) * 9 * CoutPad * 8;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(pack_conv_weight_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned*)wp3, Cout, Cin,
+                     CoutPad);
+  HDIFF_CHECK_LAUNCH("pack_conv_weight_x3_kernel");
+  return HDIFF_OK;
+}

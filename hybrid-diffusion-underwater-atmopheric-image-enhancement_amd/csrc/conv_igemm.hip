@@ -462,14 +462,14 @@ int configure(const hdiff_conv_desc* d, ConvCfg& c) {
 
 }  // namespace
 
-namespace { bool is_direct_1x1(const hdiff_conv_desc* d); }
+namespace { bool is_direct_1x1(const hdiff_conv_desc* d); bool is_x3_3x3(const hdiff_conv_desc* d); }
 
 extern "C" int hdiff_conv2d_fwd_workspace(const hdiff_conv_desc* d, int64_t* floats_out) {
   HDIFF_CHECK_ARG(floats_out, "conv2d_fwd_workspace: null pointer");
   ConvCfg c;
   const int rc = configure(d, c);
   if (rc != HDIFF_OK) return rc;
-  *floats_out = is_direct_1x1(d) ? 0 : c.splitk_floats;
+  *floats_out = (is_direct_1x1(d) || is_x3_3x3(d)) ? 0 : c.splitk_floats;
   return HDIFF_OK;
 }
 
@@ -489,7 +489,39 @@ struct Conv1x1K {
 void launch_conv1x1_direct(const Conv1x1K& k, int B, hipStream_t stream);   // conv1x1_direct.hip
 }  // namespace hdiff
 
+namespace hdiff {
+struct ConvX3K {
+  const float* x0;
+  const float* x1;
+  int C0, C1, Cin, H, W;
+  const unsigned* wp3;
+  int CoutPad, Cout;
+  const float* bias;
+  const float* gn_scale;
+  const float* gn_shift;
+  const float* addvec;
+  const float* residual;
+  float* out;
+  int tiles_x;
+};
+void launch_conv3x3_x3(const ConvX3K& k, int B, hipStream_t stream);          // conv3x3_x3.hip
+}  // namespace hdiff
+
 namespace {
+// Split-bf16 mode: a plain 3x3 / stride-1 / pad-1 conv with 16-channel-aligned inputs and a launch large enough to fill the
+// chip (small ones keep the split-K path of the fp32 kernel).
+bool is_x3_3x3(const hdiff_conv_desc* d) {
+  if (d->wp_x3 == nullptr || hdiff::contraction_mode() != HDIFF_CONTRACT_BF16X3) return false;
+  if (d->ntaps != 9 || d->in_stride != 1 || d->out_sy != 1 || d->out_oy != 0 || d->out_sx != 1 || d->out_ox != 0) return false;
+  if (d->VH != d->H || d->VW != d->W || d->OH != d->H || d->OW != d->W) return false;
+  for (int t = 0; t < 9; ++t)
+    if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1) return false;
+  const int Cin = d->C0 + d->C1;
+  if (Cin % 16 != 0 || (d->C1 != 0 && d->C0 % 16 != 0) || Cin > 4096) return false;
+  const long blocks = (long)cdiv(d->W, 32) * cdiv(d->H, 8) * cdiv(d->Cout, 64) * d->B;
+  return blocks >= 192;
+}
+
 // A plain 1x1 / stride-1 conv over a full-size output with no GroupNorm prologue and enough pixels to fill the chip goes to
 // the LDS-free GEMM kernel (small grids keep the split-K path of the implicit-GEMM kernel).
 bool is_direct_1x1(const hdiff_conv_desc* d) {
@@ -505,6 +537,14 @@ extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream)
   const int rc = configure(d, c);
   if (rc != HDIFF_OK) return rc;
   ConvK& k = c.k;
+  if (is_x3_3x3(d)) {
+    hdiff::ConvX3K q{d->x0, d->x1, d->C0, d->C1, d->C0 + d->C1, d->H, d->W, (const unsigned*)d->wp_x3, d->CoutPad, d->Cout,
+                     d->bias, d->gn_scale, d->gn_shift, d->addvec, d->residual, d->out, cdiv(d->W, 32)};
+    (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+    hdiff::launch_conv3x3_x3(q, d->B, (hipStream_t)stream);
+    HDIFF_CHECK_LAUNCH("conv3x3_x3_kernel");
+    return HDIFF_OK;
+  }
   if (is_direct_1x1(d)) {
     hdiff::Conv1x1K q{d->x0, d->x1, d->C0, d->C0 + d->C1, (long)d->H * d->W, d->wp, d->CoutPad, d->Cout, d->bias, d->addvec,
                       d->residual, d->out};

@@ -24,7 +24,7 @@ int contraction_mode() {
 
 extern "C" {
 
-int hdiff_abi_version(void) { return 1; }
+int hdiff_abi_version(void) { return 2; }
 const char* hdiff_last_error(void) { return hdiff::g_err; }
 
 int hdiff_set_contraction_mode(int mode) {

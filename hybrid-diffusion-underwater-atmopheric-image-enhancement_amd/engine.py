@@ -89,6 +89,14 @@ class PackedConv:
         self.ntaps = len(taps.dy)
         self.wp = torch.empty(self.ntaps * self.cin_pad * self.cout_pad, dtype=torch.float32, device=device)
         self.sources: List[Tuple[torch.Tensor, int, int, int, List[int], List[int], int]] = []
+        self.wp3: Optional[torch.Tensor] = None      # split-bf16 copy (standard 3x3 convs with Cin % 16 == 0), see enable_x3
+        self._x3_src: Optional[torch.Tensor] = None
+
+    def enable_x3(self, w: torch.Tensor) -> None:
+        """Also keep the weights as three bf16 pieces (conv3x3_x3.hip) -- used when the contraction mode is bf16x3."""
+        if self.ntaps == 9 and self.cin % 16 == 0 and tuple(w.shape[2:]) == (3, 3):
+            self.wp3 = torch.empty((self.cin // 16) * 9 * 3 * self.cout_pad * 8, dtype=torch.int32, device=self.wp.device)
+            self._x3_src = w
 
     def add_source(self, w: torch.Tensor, mode: int, ky: Sequence[int], kx: Sequence[int], accumulate: int) -> None:
         kh, kw = int(w.shape[2]), int(w.shape[3])
@@ -103,6 +111,9 @@ class PackedConv:
             _capi.check(lib.hdiff_pack_conv_weight(w.data_ptr(), self.wp.data_ptr(), mode, self.cout, self.cin, kh, kw,
                                                    self.ntaps, a_ky, a_kx, self.cin_pad, self.cout_pad, acc, stream),
                         "pack_conv_weight")
+        if self.wp3 is not None:
+            _capi.check(lib.hdiff_pack_conv_weight_x3(self._x3_src.data_ptr(), self.wp3.data_ptr(), self.cout, self.cin,
+                                                      self.cout_pad, stream), "pack_conv_weight_x3")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -213,6 +224,7 @@ class Plan:
         d.VH, d.VW, d.in_stride = VH, VW, in_stride
         d.out_sy, d.out_oy, d.out_sx, d.out_ox = out_map
         d.ntaps = pk.ntaps
+        d.wp_x3 = _ptr(pk.wp3)
         for i in range(pk.ntaps):
             d.tap_dy[i], d.tap_dx[i] = pk.taps.dy[i], pk.taps.dx[i]
         need = C.c_int64(0)
@@ -276,6 +288,8 @@ def _std_pack(plan: Plan, w: torch.Tensor, k: int, pad: int) -> PackedConv:
     taps = conv_taps(k, pad)
     pk = _new_pack(plan, int(w.shape[0]), int(w.shape[1]), taps)
     pk.add_source(w, 0, taps.ky, taps.kx, 0)
+    if k == 3 and pad == 1:
+        pk.enable_x3(w)
     return pk
 
 

@@ -60,6 +60,10 @@ int hdiff_pack_conv_weight(const float* w, float* wp, int mode, int Cout, int Ci
                            const int* tap_ky, const int* tap_kx, int CinPad, int CoutPad, int accumulate,
                            hdiff_stream_t stream);
 
+/* Weights of a standard 3x3 conv ([Cout][Cin][3][3], Cin % 16 == 0) as three bf16 pieces per value, laid out
+ * [Cin/16][tap][piece][CoutPad][16] for conv3x3_x3.hip; wp3 holds (Cin/16)*9*3*CoutPad*8 32-bit words. */
+int hdiff_pack_conv_weight_x3(const float* w, void* wp3, int Cout, int Cin, int CoutPad, hdiff_stream_t stream);
+
 typedef struct hdiff_conv_desc {
   /* input: virtual channel-concat of x0 [B][C0][H][W] and x1 [B][C1][H][W] (x1 may be NULL with C1 = 0);
    * replaces torch.cat([h, hs.pop()], dim=1) at ModelCondition.py:271 */
@@ -91,6 +95,10 @@ typedef struct hdiff_conv_desc {
    * channel slices whose partial sums are reduced in a fixed order; NULL = never split */
   float* splitk_ws;
   int64_t splitk_floats;
+  /* optional (ABI 2): the same weights as three bf16 pieces (hdiff_pack_conv_weight_x3).  Used instead of wp when the
+   * contraction mode is HDIFF_CONTRACT_BF16X3 and the launch is a plain 3x3 / stride-1 / pad-1 conv with Cin % 16 == 0;
+   * NULL = always the fp32-input MFMA */
+  const void* wp_x3;
 } hdiff_conv_desc;
 
 int hdiff_conv2d_fwd_workspace(const hdiff_conv_desc* d, int64_t* floats_out);

@@ -256,6 +256,36 @@ def test_flash_attention_split_bf16_overflow_falls_back(bf16x3_mode):
     close(lse, ref_lse.float(), rel=1e-5, abs_=1e-4, what="lse2 (split-bf16)")
 
 
+@pytest.mark.parametrize("C0,C1,cout,H,W,B,use_gn", [(64, 0, 64, 64, 64, 16, True), (128, 64, 128, 64, 96, 4, True),
+                                                        (32, 16, 96, 40, 72, 8, False), (256, 0, 256, 32, 32, 12, True)])
+def test_conv3x3_split_bf16_is_fp32_class(C0, C1, cout, H, W, B, use_gn, bf16x3_mode):
+    """HDIFF_CONTRACT_BF16X3 for the 3x3 convolutions (conv3x3_x3.hip): error against float64 of the same class as the
+    fp32-MFMA kernel's, with the fused GroupNorm/Swish prologue, concat input, bias + vector + residual epilogue."""
+    lib = bf16x3_mode
+    g = torch.Generator().manual_seed(C0 * 7 + cout + H)
+    cin = C0 + C1
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    vec = torch.randn(B, cout, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g)
+    gn = (torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g) * 0.3) if use_gn else None
+    xin = (x0 if x1 is None else torch.cat([x0, x1], dim=1)).double()
+    if use_gn:
+        a = xin * gn[0].double()[:, :, None, None] + gn[1].double()[:, :, None, None]
+        xin = a * torch.sigmoid(a)
+    want = F.conv2d(xin, w.double(), b.double(), padding=1) + vec.double()[:, :, None, None] + res.double()
+    got_x3 = run_conv(x0, x1, w, b, 3, 1, gn=gn, addvec=vec, residual=res)
+    _capi.check(lib.hdiff_set_contraction_mode(0))
+    got_f32 = run_conv(x0, x1, w, b, 3, 1, gn=gn, addvec=vec, residual=res)
+    _capi.check(lib.hdiff_set_contraction_mode(1))
+    assert not torch.equal(got_x3, got_f32), "the split-bf16 kernel did not run"
+    close(got_x3, want.float(), rel=1e-5, what="conv3x3 split-bf16")
+    rms = lambda t: (t.double().cpu() - want).pow(2).mean().sqrt().item()
+    assert rms(got_x3) <= 1.5 * rms(got_f32) + 1e-12, (rms(got_x3), rms(got_f32))
+
+
 def test_linear_rows_and_gather():
     g = torch.Generator().manual_seed(1)
     table = torch.randn(20, 128, generator=g)
