@@ -20,10 +20,10 @@ _CONTRACT = {"f32": 0, "bf16x3": 1}
 
 
 def set_contraction_mode(mode: str) -> None:
-    """How the attention contractions run (process-wide; launch plans captured afterwards keep the mode they saw).
+    """How the attention and 3x3-convolution contractions run (process-wide; graphs captured afterwards keep the mode they saw).
 
     ``"f32"`` (default): the fp32-input MFMA.  ``"bf16x3"``: every fp32 operand as three bf16 pieces, six products on the
-    bf16 MFMA with fp32 accumulation -- fp32-class accuracy (tests/test_gpu_ops.py), about 1.5x faster attention.
+    bf16 MFMA with fp32 accumulation -- fp32-class accuracy (tests/test_gpu_ops.py), about 1.5x faster kernels.
     The environment variable ``HDIFF_CONTRACT`` sets the initial value."""
     if mode not in _CONTRACT:
         raise ValueError(f"contraction mode must be one of {sorted(_CONTRACT)}, got {mode!r}")

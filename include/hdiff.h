@@ -32,11 +32,14 @@ int hdiff_abi_version(void);
 const char* hdiff_last_error(void);
 /* Number of HIP devices visible (0 without a GPU); never initialises a context. */
 int hdiff_device_count(void);
-/* How the fp32 matrix contractions of the attention core are carried out (process-wide, read at launch time):
- *   HDIFF_CONTRACT_F32    (0, default)  fp32-input MFMA (v_mfma_f32_16x16x4_f32)
+/* How the fp32 matrix contractions of the attention core and of the 3x3 convolutions are carried out (process-wide, read
+ * at launch time):
+ *   HDIFF_CONTRACT_F32    (0, default)  fp32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2)
  *   HDIFF_CONTRACT_BF16X3 (1)           each fp32 operand as three bf16 pieces, the six products with i+j<=2 on the bf16
  *                                       MFMA with fp32 accumulation: fp32-class error (about 2^-22 relative per product),
- *                                       2-3x faster; shapes it does not cover silently use the fp32 kernels.
+ *                                       about 1.5x faster; shapes it does not cover silently use the fp32 kernels
+ *                                       (attention: d_head 16/32, L % 64 == 0; conv: 3x3 stride 1 with Cin % 16 == 0 and a
+ *                                       descriptor that carries wp_x3).
  * The initial value comes from the environment variable HDIFF_CONTRACT ("f32" | "bf16x3"). */
 enum { HDIFF_CONTRACT_F32 = 0, HDIFF_CONTRACT_BF16X3 = 1 };
 int hdiff_set_contraction_mode(int mode);
