@@ -150,11 +150,11 @@ class GaussianDiffusionSampler(nn.Module):
             raise TypeError("unsupported operand type(s) for /: 'int' and 'NoneType'")             # :243 with ddim_step=None
         inject = (not ddim) and noise_by_step is not None
         seed = 0 if (ddim or inject) else int(torch.empty((), dtype=torch.int64).random_().item())
-        key = (B, H, W, str(dev), int(ddim_step) if ddim else None, inject, seed)
+        key = (B, H, W, str(dev), int(ddim_step) if ddim else None, inject, seed, lib.hdiff_get_contraction_mode())
         sp = self._plans.get(key)
         if sp is None or sp.unet is not self.model.plan_for(B, H, W, dev, True):
             sp = _StepPlan(self, B, H, W, dev, int(ddim_step) if ddim else None, inject, seed)
-            self._plans = {key: sp}                                  # a graph bakes its seed: keep one live plan
+            self._plans = {key: sp}                                  # a graph bakes its seed and contraction mode: keep one live plan
         self.model.plan_for(B, H, W, dev, True)                     # repack weights if they changed
         self.model.dynamic_forward(torch.cat([img, img], dim=1))    # the reference runs it on every call (requires_grad only)
         y = torch.randn_like(img) if y_T is None else y_T            # :226 / :239
