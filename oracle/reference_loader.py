@@ -87,3 +87,21 @@ def load_sampler_b() -> types.ModuleType:
     exec("import torch\nimport torch.nn as nn\nimport torch.nn.functional as F\n", mod.__dict__)
     exec(compile("".join(kept), path, "exec"), mod.__dict__)
     return mod
+
+
+def load_uw_metrics() -> types.ModuleType:
+    """The numpy/scipy-only quality measures of metrics/metrics.py (``mu_a`` ... ``getUIQM``, ``eme``, ``logamee``; lines from
+    ``def mu_a`` up to ``class FID``).  The file's own imports need scikit-image, torchvision and OpenCV (absent: ordinary
+    ImportError), so only that span is compiled, in place; ``nmetrics`` inside it is defined but never called here."""
+    path = os.path.join(REFERENCE_ROOT, "metrics", "metrics.py")
+    with open(path, "r") as fh:
+        lines = fh.readlines()
+    a = next(i for i, l in enumerate(lines) if l.startswith("def mu_a"))
+    b = next(i for i, l in enumerate(lines) if l.startswith("class FID"))
+    kept = ["\n"] * len(lines)
+    kept[a:b] = lines[a:b]
+    mod = types.ModuleType("_ref_metrics")
+    mod.__file__ = path
+    exec("import math\nimport numpy as np\nfrom scipy import ndimage\n", mod.__dict__)
+    exec(compile("".join(kept), path, "exec"), mod.__dict__)
+    return mod
