@@ -32,3 +32,29 @@ def test_train_then_eval_tiny(tmp_path):
     assert tuple(imgs.shape) == (8, 3, 16, 16) and float(imgs.min()) >= 0 and float(imgs.max()) <= 1
     assert os.path.isfile(os.path.join(cfg["sampled_dir"], "sampled.png"))
     assert os.path.isfile(os.path.join(cfg["sampled_dir"], "noisy.png"))
+
+
+def test_bench_json_contract_small():
+    """bench.py prints ONE JSON line with the driver's fields (run at 64x64, batch 2 so that it takes seconds)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--size", "64", "--batch", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches_timed"] == 2 * 2 and r["avg_launch_ms"] > 0
+    alt = d["config"]["other_contract_mode"]
+    assert alt["contract"] == "bf16x3" and alt["ms_per_step"] > 0
