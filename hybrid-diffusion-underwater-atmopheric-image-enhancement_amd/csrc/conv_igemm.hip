@@ -36,6 +36,7 @@ struct ConvK {
   int OH, OW, VH, VW, in_stride, out_sy, out_oy, out_sx, out_ox;
   int ntaps, dy_min, dx_min, PH, PW, PWp, PLANE, XFLOATS, WFLOATS;
   int tw_log2, TH, tiles_x;
+  int rows;                        // patch rows actually staged: min(TH, VH) (tiny images: the tile is taller than the image)
   int nx, nw;                      // staging slots in use per thread (activation floats, weight float4s)
   int B, ksplit, chunks_per_split; // split-K over input-channel chunks for small grids (partials -> conv_splitk_reduce)
   float* partial;                  // [ksplit][B][Cout][VH*VW]
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
   for (int nt = 0; nt < WN; ++nt) {
     const int pidx = (wave * WN + nt) * 32 + l31;
-    pixoff[nt] = ((pidx >> p.tw_log2) * p.PWp + (pidx & TWm1)) * p.in_stride;
+    // tile rows past the staged patch (only when the tile is taller than the whole image) alias its last row: never stored
+    pixoff[nt] = (min(pidx >> p.tw_log2, p.rows - 1) * p.PWp + (pidx & TWm1)) * p.in_stride;
   }
 
   f32x16 acc[2][WN];
@@ -416,7 +418,8 @@ int configure(const hdiff_conv_desc* d, ConvCfg& c) {
   const int TW = 1 << twl;
   k.TH = BN / TW;
   k.tiles_x = cdiv(d->VW, TW);
-  k.PH = (k.TH - 1) * d->in_stride + (dy_max - dy_min + 1);
+  k.rows = k.TH < d->VH ? k.TH : d->VH;
+  k.PH = (k.rows - 1) * d->in_stride + (dy_max - dy_min + 1);
   k.PW = (TW - 1) * d->in_stride + (dx_max - dx_min + 1);
   k.PWp = k.PW | 1;
   k.PLANE = k.PH * k.PWp;

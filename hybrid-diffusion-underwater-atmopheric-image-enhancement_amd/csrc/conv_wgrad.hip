@@ -36,6 +36,7 @@ struct WgradK {
   int VH, VW, in_stride, out_sy, out_oy, out_sx, out_ox;
   int ntaps, dy_min, dx_min, PH, PW, PWp, PLANE;
   int tw_log2, TH, tiles_x, tiles_per_image, total_tiles;
+  int rows;                        // patch rows actually staged: min(TH, VH)
   int CKW, ncol, nt_used, nx;
   int CinPad, CoutPad, nsplit;
   float* dwp;
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradK p) {
 #pragma unroll 4
       for (int kk = 0; kk < BNP / 8; ++kk) {
         const int k = kbeg + 2 * kk + h;
-        const int pixoff = ((k >> p.tw_log2) * p.PWp + (k & TWm1)) * p.in_stride;
+        // rows past the staged patch (tile taller than the image) alias its last row: their dY is zero
+        const int pixoff = (min(k >> p.tw_log2, p.rows - 1) * p.PWp + (k & TWm1)) * p.in_stride;
         const float a0 = sY[l31 * DYROW + k];
         const float a1 = sY[(32 + l31) * DYROW + k];
 #pragma unroll
@@ -314,7 +316,8 @@ extern "C" int hdiff_conv2d_wgrad(const hdiff_conv_wgrad_desc* d, float* dwp, in
   k.tiles_x = cdiv(d->VW, TW);
   k.tiles_per_image = k.tiles_x * cdiv(d->VH, k.TH);
   k.total_tiles = d->B * k.tiles_per_image;
-  k.PH = (k.TH - 1) * d->in_stride + (dy_max - dy_min + 1);
+  k.rows = k.TH < d->VH ? k.TH : d->VH;
+  k.PH = (k.rows - 1) * d->in_stride + (dy_max - dy_min + 1);
   k.PW = (TW - 1) * d->in_stride + (dx_max - dx_min + 1);
   k.PWp = k.PW | 1;
   k.PLANE = k.PH * k.PWp;

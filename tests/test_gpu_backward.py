@@ -236,3 +236,41 @@ def test_dropout_train_mode_statistics_and_grad():
                                                torch.cuda.current_stream().cuda_stream))
     kept = (mask > 0).float().mean().item()
     assert abs(kept - 0.85) < 3e-3 and abs(mask.max().item() - 1 / 0.85) < 1e-6
+
+
+def test_training_step_on_tiny_images_matches_oracle_autograd():
+    """8x8 inputs drive the four-level layout down to 1x1 feature maps (conv tiles taller than the image, attention over one
+    token, GroupNorm over two values per group).  That problem is ill conditioned in fp32 -- the CPU oracle in fp32 is itself
+    1e-3 away from float64 autograd -- so the bar is: no further than 4x the CPU-fp32 error from the float64 gradients."""
+    torch.manual_seed(21)
+    cfgd = dict(T=10, num_labels=4, ch=32, ch_mult=[1, 2, 2, 2], num_res_blocks=1, dropout=0.0)
+    m = MC.UNet(**cfgd).train()
+    cfg = O.UNetConfig(T=10, num_labels=4, ch=32, ch_mult=(1, 2, 2, 2), num_res_blocks=1)
+    g = torch.Generator().manual_seed(4)
+    B = 3
+    x0 = torch.rand(B, 3, 8, 8, generator=g) * 2 - 1
+    lab = torch.tensor([1, 0, 3])
+    t = torch.tensor([0, 5, 9])
+    noise = torch.randn(B, 3, 8, 8, generator=g)
+    names = ["head.weight", "downblocks.6.block1.2.weight", "middleblocks.0.attn.in_proj_weight", "upblocks.0.block2.3.weight",
+             "upblocks.8.t.weight", "tail.2.bias", "time_embedding.timembedding.1.weight", "cond_embedding.condEmbedding.0.weight"]
+    sched = O.trainer_schedule(1e-4, 0.02, 10)
+    grads = {}
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        sd = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
+        loss_ref = O.trainer_loss(sd, cfg, sched, x0.to(dt), lab, t, noise.to(dt))
+        (loss_ref.sum() / B ** 2.).backward()
+        grads[tag] = ({n: sd[n].grad.double() for n in names}, loss_ref.detach().double())
+    md = m.to(DEV)
+    tr = DC.GaussianDiffusionTrainer(md, 1e-4, 0.02, 10).to(DEV)
+    loss = tr(x0.to(DEV), lab.to(DEV), t=t.to(DEV), noise=noise.to(DEV))
+    (loss.sum() / B ** 2.).backward()
+    ref_loss = grads["f64"][1]
+    assert (loss.detach().cpu().double() - ref_loss).abs().max().item() <= 4 * (grads["f32"][1] - ref_loss).abs().max().item() + 1e-5
+    params = dict(md.named_parameters())
+    for n in names:
+        ref = grads["f64"][0][n]
+        scale = ref.abs().max().item()
+        e_cpu = (grads["f32"][0][n] - ref).abs().max().item()
+        e_hip = (params[n].grad.detach().cpu().double() - ref).abs().max().item()
+        assert e_hip <= 4 * e_cpu + 1e-6 * scale, (n, e_hip, e_cpu, scale)

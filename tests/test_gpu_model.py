@@ -205,3 +205,29 @@ def test_unet_vs_oracle_larger_shape():
     e = maxerr(y, ref)
     print(f"unet 64x64 two-level max err {e:.3e}")
     assert e < 2e-4
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 8, 8), (1, 16, 24), (5, 8, 40)])
+def test_unet_edge_shapes_vs_oracle(B, H, W):
+    """Smallest legal sizes of the four-level default layout (8x8 reaches a 1x1 bottom level: attention over ONE token),
+    non-square images and odd batches, against the CPU oracle; plus the shortest sampler the reference can run (T = 2: its
+    variance table is empty for T = 1)."""
+    torch.manual_seed(11)
+    cfgd = dict(T=10, num_labels=4, ch=32, ch_mult=[1, 2, 2, 2], num_res_blocks=1, dropout=0.0)
+    m = MC.UNet(**cfgd).eval()
+    cfg = O.UNetConfig(T=10, num_labels=4, ch=32, ch_mult=(1, 2, 2, 2), num_res_blocks=1)
+    g = torch.Generator().manual_seed(B * 100 + H + W)
+    x = torch.randn(B, 3, H, W, generator=g)
+    t = torch.randint(0, 10, (B,), generator=g)
+    lab = torch.randint(0, 5, (B,), generator=g)          # includes the unconditional label 0 (padding row)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.unet_forward(sd, cfg, x, t, lab)
+        md = m.to(DEV)
+        y = md(x.to(DEV), t.to(DEV), lab.to(DEV))
+        assert maxerr(y, ref) < 2e-4 * max(1.0, ref.abs().max().item())
+        s2 = DC.GaussianDiffusionSampler(md, 1e-4, 0.02, 2, w=0.0).to(DEV)
+        z = torch.randn(2, B, 3, H, W, generator=g)
+        out = s2(x.to(DEV), lab.to(DEV), noise_by_step=z.to(DEV))
+        want = O.sampler_forward(sd, cfg, 1e-4, 0.02, 2, 0.0, x, lab, list(z))
+        assert maxerr(out, want) < 2e-4
