@@ -57,8 +57,10 @@ class GaussianDiffusionTrainer(nn.Module):
         B = int(x_0.shape[0])
         if t is None:
             t = torch.randint(self.T, size=(B,), device=x_0.device)
+        t = t.to(device=x_0.device, dtype=torch.int64).contiguous()      # the gather kernels read int64 indices
         if noise is None:
             noise = torch.randn_like(x_0)
+        E.require_gpu_tensor(noise, "noise")
         sa, sb = self.sqrt_alphas_bar.float(), self.sqrt_one_minus_alphas_bar.float()
         x_t = torch.empty_like(x_0)
         s = _stream(x_0.device)
