@@ -1,5 +1,5 @@
 """Drop-in for the reference's ``DiffusionFreeGuidence/TrainCondition.py``: ``train(modelConfig)`` and ``eval(modelConfig)``
-with the same config keys (MainCondition.py:5-29) and the same loop semantics:
+driven by the same config dict (keys of MainCondition.py:5-29) with the same loop semantics:
 
   train: AdamW(lr, weight_decay=1e-4); CosineAnnealingLR(T_max=epoch) behind GradualWarmupScheduler(multiplier,
          warm_epoch=epoch//10), stepped per epoch; labels + 1; with probability 0.1 the WHOLE batch's labels are zeroed
@@ -15,7 +15,7 @@ torchvision is installed).  Optional keys, all with reference-equivalent default
 per-rank shard of every epoch, ONE mean all-reduce of the gradients per step (hdiff_amd.parallel), rank-0 checkpoints.
 """
 import os
-from typing import Dict
+from typing import Dict, List
 
 import numpy as np
 import torch
@@ -33,6 +33,10 @@ except Exception:  # pragma: no cover
     def tqdm(it, **_):
         return it
 
+WEIGHT_DECAY = 1e-4          # reference :39-40
+LABEL_DROP_PROBABILITY = 0.1  # reference :57: classifier-free guidance trains the unconditional branch on 10 % of the batches
+EVAL_LABEL_GROUPS = 10       # reference :79
+
 
 def _dataset(cfg: Dict):
     kind = cfg.get("dataset", "folder" if cfg.get("data_dir") else "synthetic")
@@ -43,9 +47,8 @@ def _dataset(cfg: Dict):
     if kind == "cifar10":
         from torchvision import transforms
         from torchvision.datasets import CIFAR10
-        return CIFAR10(root='./CIFAR10', train=True, download=True,
-                       transform=transforms.Compose([transforms.ToTensor(),
-                                                     transforms.Normalize((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))]))
+        to_unit_range = transforms.Compose([transforms.ToTensor(), transforms.Normalize((0.5,) * 3, (0.5,) * 3)])
+        return CIFAR10(root="./CIFAR10", train=True, download=True, transform=to_unit_range)
     raise ValueError(f"unknown dataset kind {kind!r}")
 
 
@@ -59,88 +62,86 @@ def _epoch_indices(n: int, epoch: int, rank: int, world: int, seed: int = 0):
     return perm
 
 
-def train(modelConfig: Dict):
+def _denoiser(cfg: Dict, device) -> UNet:
+    return UNet(T=cfg["T"], num_labels=cfg.get("num_labels", 10), ch=cfg["channel"], ch_mult=cfg["channel_mult"],
+                num_res_blocks=cfg["num_res_blocks"], dropout=cfg["dropout"]).to(device)
+
+
+def _weights_path(cfg: Dict, name: str) -> str:
+    return os.path.join(cfg["save_dir"], name)
+
+
+def _eval_labels(batch: int, num_labels: int) -> torch.Tensor:
+    """Sample i gets class min(i // (batch // 10), classes - 1), then + 1 because 0 is the unconditional label (:79-87)."""
+    width = max(1, batch // EVAL_LABEL_GROUPS)
+    top = min(EVAL_LABEL_GROUPS, num_labels) - 1
+    return torch.tensor([min(i // width, top) for i in range(batch)], dtype=torch.long) + 1
+
+
+def train(modelConfig: Dict) -> List[float]:
+    cfg = modelConfig
     rank, local, world = parallel.init_from_env()
-    device = torch.device(modelConfig["device"]) if world == 1 else torch.device("cuda", local)
-    dataset = _dataset(modelConfig)
-    num_labels = modelConfig.get("num_labels", 10)
+    device = torch.device(cfg["device"]) if world == 1 else torch.device("cuda", local)
+    data = _dataset(cfg)
 
-    net_model = UNet(T=modelConfig["T"], num_labels=num_labels, ch=modelConfig["channel"],
-                     ch_mult=modelConfig["channel_mult"], num_res_blocks=modelConfig["num_res_blocks"],
-                     dropout=modelConfig["dropout"]).to(device)
-    if modelConfig["training_load_weight"] is not None:
-        net_model.load_state_dict(torch.load(os.path.join(modelConfig["save_dir"], modelConfig["training_load_weight"]),
-                                             map_location=device), strict=False)
+    net = _denoiser(cfg, device)
+    if cfg["training_load_weight"] is not None:
+        net.load_state_dict(torch.load(_weights_path(cfg, cfg["training_load_weight"]), map_location=device), strict=False)
         print("Model weight load down.")
-    parallel.broadcast_parameters_(net_model.parameters())
-    optimizer = torch.optim.AdamW(net_model.parameters(), lr=modelConfig["lr"], weight_decay=1e-4)
-    cosine = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=optimizer, T_max=modelConfig["epoch"], eta_min=0,
-                                                        last_epoch=-1)
-    warmup = GradualWarmupScheduler(optimizer=optimizer, multiplier=modelConfig["multiplier"],
-                                    warm_epoch=modelConfig["epoch"] // 10, after_scheduler=cosine)
-    trainer = GaussianDiffusionTrainer(net_model, modelConfig["beta_1"], modelConfig["beta_T"], modelConfig["T"]).to(device)
-    params = [p for p in net_model.parameters()]
-    os.makedirs(modelConfig["save_dir"], exist_ok=True)
-    history = []
+    parallel.broadcast_parameters_(net.parameters())
+    weights = list(net.parameters())
+    opt = torch.optim.AdamW(weights, lr=cfg["lr"], weight_decay=WEIGHT_DECAY)
+    schedule = GradualWarmupScheduler(
+        optimizer=opt, multiplier=cfg["multiplier"], warm_epoch=cfg["epoch"] // 10,
+        after_scheduler=torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=opt, T_max=cfg["epoch"], eta_min=0, last_epoch=-1))
+    objective = GaussianDiffusionTrainer(net, cfg["beta_1"], cfg["beta_T"], cfg["T"]).to(device)
+    os.makedirs(cfg["save_dir"], exist_ok=True)
+    step_cap = cfg.get("max_steps_per_epoch", 1 << 30)
+    losses: List[float] = []
 
-    for e in range(modelConfig["epoch"]):
-        idx = _epoch_indices(len(dataset), e, rank, world)
-        loader = DataLoader(Subset(dataset, idx), batch_size=modelConfig["batch_size"], shuffle=False,
-                            num_workers=modelConfig.get("num_workers", 4), drop_last=True, pin_memory=True)
-        bar = tqdm(loader, dynamic_ncols=True, disable=rank != 0)
-        for step, (images, labels) in enumerate(bar):
-            if step >= modelConfig.get("max_steps_per_epoch", 1 << 30):
+    for epoch in range(cfg["epoch"]):
+        shard = Subset(data, _epoch_indices(len(data), epoch, rank, world))
+        batches = DataLoader(shard, batch_size=cfg["batch_size"], shuffle=False, num_workers=cfg.get("num_workers", 4),
+                             drop_last=True, pin_memory=True)
+        progress = tqdm(batches, dynamic_ncols=True, disable=rank != 0)
+        for it, (images, domains) in enumerate(progress):
+            if it >= step_cap:
                 break
-            b = images.shape[0]
-            optimizer.zero_grad()
             x_0 = images.to(device)
-            labels = torch.as_tensor(labels).to(device) + 1
-            if np.random.rand() < 0.1:
+            labels = torch.as_tensor(domains).to(device) + 1
+            if np.random.rand() < LABEL_DROP_PROBABILITY:          # one draw per batch, on the host, like the reference
                 labels = torch.zeros_like(labels)
-            loss = trainer(x_0, labels).sum() / b ** 2.
+            opt.zero_grad()
+            loss = objective(x_0, labels).sum() / x_0.shape[0] ** 2.
             loss.backward()
-            parallel.allreduce_mean_grads_(params)
-            torch.nn.utils.clip_grad_norm_(net_model.parameters(), modelConfig["grad_clip"])
-            optimizer.step()
-            lv = loss.item()
-            history.append(lv)
-            if hasattr(bar, "set_postfix"):
-                bar.set_postfix(ordered_dict={"epoch": e, "loss: ": lv, "img shape: ": tuple(x_0.shape),
-                                              "LR": optimizer.state_dict()['param_groups'][0]["lr"]})
-        warmup.step()
+            parallel.allreduce_mean_grads_(weights)
+            torch.nn.utils.clip_grad_norm_(weights, cfg["grad_clip"])
+            opt.step()
+            losses.append(loss.item())
+            if hasattr(progress, "set_postfix"):
+                progress.set_postfix(ordered_dict={"epoch": epoch, "loss: ": losses[-1], "img shape: ": tuple(x_0.shape),
+                                                   "LR": opt.param_groups[0]["lr"]})
+        schedule.step()
         if rank == 0:
-            torch.save(net_model.state_dict(), os.path.join(modelConfig["save_dir"], 'ckpt_' + str(e) + "_.pt"))
-    return history
+            torch.save(net.state_dict(), _weights_path(cfg, f"ckpt_{epoch}_.pt"))
+    return losses
 
 
-def eval(modelConfig: Dict):
-    device = torch.device(modelConfig["device"])
-    num_labels = modelConfig.get("num_labels", 10)
+def eval(modelConfig: Dict) -> torch.Tensor:
+    cfg = modelConfig
+    device = torch.device(cfg["device"])
+    batch, side = cfg["batch_size"], cfg["img_size"]
     with torch.no_grad():
-        step = max(1, int(modelConfig["batch_size"] // 10))
-        labelList, k = [], 0
-        for i in range(1, modelConfig["batch_size"] + 1):
-            labelList.append(torch.ones(size=[1]).long() * k)
-            if i % step == 0 and k < min(10, num_labels) - 1:
-                k += 1
-        labels = torch.cat(labelList, dim=0).long().to(device) + 1
+        labels = _eval_labels(batch, cfg.get("num_labels", 10)).to(device)
         print("labels: ", labels)
-        model = UNet(T=modelConfig["T"], num_labels=num_labels, ch=modelConfig["channel"],
-                     ch_mult=modelConfig["channel_mult"], num_res_blocks=modelConfig["num_res_blocks"],
-                     dropout=modelConfig["dropout"]).to(device)
-        ckpt = torch.load(os.path.join(modelConfig["save_dir"], modelConfig["test_load_weight"]), map_location=device)
-        model.load_state_dict(ckpt)
+        net = _denoiser(cfg, device)
+        net.load_state_dict(torch.load(_weights_path(cfg, cfg["test_load_weight"]), map_location=device))
         print("model load weight done.")
-        model.eval()
-        sampler = GaussianDiffusionSampler(model, modelConfig["beta_1"], modelConfig["beta_T"], modelConfig["T"],
-                                           w=modelConfig["w"]).to(device)
-        noisyImage = torch.randn(size=[modelConfig["batch_size"], 3, modelConfig["img_size"], modelConfig["img_size"]],
-                                 device=device)
-        saveNoisy = torch.clamp(noisyImage * 0.5 + 0.5, 0, 1)
-        save_image(saveNoisy, os.path.join(modelConfig["sampled_dir"], modelConfig["sampledNoisyImgName"]),
-                   nrow=modelConfig["nrow"])
-        sampledImgs = sampler(noisyImage, labels)
-        sampledImgs = sampledImgs * 0.5 + 0.5  # [0 ~ 1]
-        save_image(sampledImgs, os.path.join(modelConfig["sampled_dir"], modelConfig["sampledImgName"]),
-                   nrow=modelConfig["nrow"])
-        return sampledImgs
+        net.eval()
+        sampler = GaussianDiffusionSampler(net, cfg["beta_1"], cfg["beta_T"], cfg["T"], w=cfg["w"]).to(device)
+        x_T = torch.randn(size=[batch, 3, side, side], device=device)
+        save_image(torch.clamp(x_T * 0.5 + 0.5, 0, 1), os.path.join(cfg["sampled_dir"], cfg["sampledNoisyImgName"]),
+                   nrow=cfg["nrow"])
+        images = sampler(x_T, labels) * 0.5 + 0.5                   # [-1, 1] -> [0, 1]
+        save_image(images, os.path.join(cfg["sampled_dir"], cfg["sampledImgName"]), nrow=cfg["nrow"])
+        return images

@@ -1,9 +1,11 @@
 """Drop-in for the reference's ``Scheduler.py``: ``GradualWarmupScheduler(optimizer, multiplier, warm_epoch, after_scheduler)``.
 
-Linear warm-up of every base learning rate from ``base`` to ``base * multiplier`` over ``warm_epoch`` epochs, then hand-over
-to ``after_scheduler`` (the reference pairs it with CosineAnnealingLR, TrainCondition.py:41-44) whose base rates are
-re-based to ``base * multiplier`` at the hand-over.  The learning-rate sequence is pinned against the reference's
-(tests/golden/lr_schedule.json).
+Every base learning rate ramps linearly from ``base`` (epoch 0) to ``base * multiplier`` (epoch ``warm_epoch``); from then on
+``after_scheduler`` -- the reference pairs it with CosineAnnealingLR (TrainCondition.py:41-44) -- takes over, with its own
+base rates re-based to ``base * multiplier`` at the hand-over and its epoch counter starting there.  The resulting
+learning-rate sequence is pinned against the reference's (tests/golden/lr_schedule.json, equal to 1e-12).
+
+Public attributes keep the reference's names: ``multiplier``, ``total_epoch``, ``after_scheduler``, ``finished``.
 """
 from torch.optim.lr_scheduler import LRScheduler
 
@@ -13,24 +15,31 @@ class GradualWarmupScheduler(LRScheduler):
         self.multiplier = multiplier
         self.total_epoch = warm_epoch
         self.after_scheduler = after_scheduler
-        self.finished = False
+        self.finished = False          # True once the follow-up scheduler has been re-based and is in charge
         super().__init__(optimizer)
 
-    def _warm(self, base_lr):
-        return base_lr * ((self.multiplier - 1.0) * self.last_epoch / self.total_epoch + 1.0)
+    def _ramp(self) -> float:
+        """Factor on the base rate during warm-up: 1 at epoch 0, ``multiplier`` at ``total_epoch``."""
+        return 1.0 + (self.multiplier - 1.0) * self.last_epoch / self.total_epoch
+
+    def _peak(self):
+        return [base * self.multiplier for base in self.base_lrs]
 
     def get_lr(self):
-        if self.last_epoch <= self.total_epoch:
-            return [self._warm(b) for b in self.base_lrs]
-        if self.after_scheduler is None:
-            return [b * self.multiplier for b in self.base_lrs]
+        warming_up = self.last_epoch <= self.total_epoch
+        if warming_up:
+            factor = self._ramp()
+            return [base * factor for base in self.base_lrs]
+        follow_up = self.after_scheduler
+        if follow_up is None:
+            return self._peak()
         if not self.finished:
-            self.after_scheduler.base_lrs = [b * self.multiplier for b in self.base_lrs]
+            follow_up.base_lrs = self._peak()
             self.finished = True
-        return self.after_scheduler.get_lr()
+        return follow_up.get_lr()
 
     def step(self, epoch=None, metrics=None):
-        if self.finished and self.after_scheduler is not None:
-            self.after_scheduler.step(None if epoch is None else epoch - self.total_epoch)
-        else:
-            super().step(epoch)
+        handed_over = self.finished and self.after_scheduler is not None
+        if not handed_over:
+            return super().step(epoch)
+        self.after_scheduler.step(None if epoch is None else epoch - self.total_epoch)
