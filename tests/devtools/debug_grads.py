@@ -1,7 +1,7 @@
 """Dev tool: per-parameter gradient error of the HIP training path vs torch autograd through the CPU oracle."""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import hdiff_amd
 from hdiff_amd.DiffusionFreeGuidence import ModelCondition as MC, DiffusionCondition as DC
 from oracle import cpu_path as O

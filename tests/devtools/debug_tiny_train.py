@@ -1,5 +1,5 @@
 """Dev tool: gradients of a tiny-image training step (HIP and CPU fp32) against float64 autograd through the oracle."""
-import sys; sys.path.insert(0,'/root/repo')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, hdiff_amd
 from hdiff_amd.DiffusionFreeGuidence import DiffusionCondition as DC, ModelCondition as MC
 from oracle import cpu_path as O

@@ -1,6 +1,6 @@
 """Dev tool: per-block comparison of the DynamicUNet launch plan against the CPU oracle (small golden model)."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import hdiff_amd
 from hdiff_amd import engine as E
