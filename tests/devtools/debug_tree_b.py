@@ -8,11 +8,9 @@ from hdiff_amd.diffusion.Model import DynamicUNet
 from hdiff_amd.DiffusionFreeGuidence.ModelCondition import _params_of
 from oracle import cpu_path_b as OB
 
-d = np.load(os.path.join(ROOT, "tests/golden/dyn_unet_small.npz"))
-cfg = json.loads(bytes(d["cfg_json"]).decode())
-m = DynamicUNet(**cfg).eval()
-sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd/")}
-m.load_state_dict(sd)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _tree_b_small import load_small_dyn_unet
+d, cfg, m, sd = load_small_dyn_unet()
 m = m.to("cuda:0")
 ocfg = OB.DynUNetConfig(T=cfg["T"], ch=cfg["ch"], ch_mult=tuple(cfg["ch_mult"]), num_res_blocks=cfg["num_res_blocks"])
 tag = sys.argv[1] if len(sys.argv) > 1 else "s16"

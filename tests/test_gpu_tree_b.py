@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hdiff_amd  # noqa: E402
 from hdiff_amd import _capi  # noqa: E402
 from hdiff_amd.diffusion.Diffusion import GaussianDiffusionSampler  # noqa: E402
@@ -28,11 +29,8 @@ def T(a):
 
 
 def small_model():
-    d = np.load(os.path.join(GOLDEN, "dyn_unet_small.npz"))
-    cfg = json.loads(bytes(d["cfg_json"]).decode())
-    m = DynamicUNet(**cfg).eval()
-    sd = {k[3:]: T(d[k]) for k in d.files if k.startswith("sd/")}
-    m.load_state_dict(sd, strict=True)
+    from _tree_b_small import load_small_dyn_unet
+    d, cfg, m, sd = load_small_dyn_unet()
     ocfg = OB.DynUNetConfig(T=cfg["T"], ch=cfg["ch"], ch_mult=tuple(cfg["ch_mult"]), num_res_blocks=cfg["num_res_blocks"])
     return d, m.to(DEV), ocfg, sd
 

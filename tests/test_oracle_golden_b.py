@@ -9,6 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import cpu_path_b as OB  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -19,9 +20,8 @@ def T(a):
 
 
 def load_small():
-    d = np.load(os.path.join(GOLDEN, "dyn_unet_small.npz"))
-    cfg = json.loads(bytes(d["cfg_json"]).decode())
-    sd = {k[3:]: T(d[k]) for k in d.files if k.startswith("sd/")}
+    from _tree_b_small import load_small_dyn_unet
+    d, cfg, _, sd = load_small_dyn_unet()
     return d, OB.DynUNetConfig(T=cfg["T"], ch=cfg["ch"], ch_mult=tuple(cfg["ch_mult"]), num_res_blocks=cfg["num_res_blocks"]), sd
 
 
