@@ -58,8 +58,9 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float*
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int qblk0 = blockIdx.x * QB + wave * (16 * NQ);
+  const TileId tile = xcd_tile();
+  const int head = tile.head, b = tile.b;
+  const int qblk0 = tile.x * QB + wave * (16 * NQ);
   const float* qbase = qkv + ((size_t)b * 3 * C + (size_t)head * D) * L;
   const float* kbase = qbase + (size_t)C * L;
   const float* vbase = kbase + (size_t)C * L;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float*
   if (check) {
     // second pass behind mha_flash_fwd_fast_kernel: only query blocks it flagged (NaN in their first output row) are
     // recomputed here with the overflow-proof running max; everything else exits at once
-    const int q = blockIdx.x * QB + tid;
+    const int q = tile.x * QB + tid;
     const bool flagged = (tid < QB) && (q < L) && isnan(out[((size_t)b * C + (size_t)head * D) * L + q]);
     if (!__syncthreads_or(flagged)) return;
   }
@@ -302,8 +303,9 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int qblk0 = blockIdx.x * QB + wave * (16 * NQ);
+  const TileId tile = xcd_tile();
+  const int head = tile.head, b = tile.b;
+  const int qblk0 = tile.x * QB + wave * (16 * NQ);
   const float* qbase = qkv + ((size_t)b * 3 * C + (size_t)head * D) * L;
   const float* kbase = qbase + (size_t)C * L;
   const float* vbase = kbase + (size_t)C * L;

@@ -77,8 +77,9 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_bwd_dq_kernel(const float* __
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
-  const int qblk0 = blockIdx.x * (64 * NQ) + wave * (16 * NQ);
+  const TileId tile = xcd_tile();
+  const int head = tile.head, b = tile.b, heads = gridDim.y;
+  const int qblk0 = tile.x * (64 * NQ) + wave * (16 * NQ);
   const float* qbase = qkv + ((size_t)b * 3 * C + (size_t)head * D) * L;
   const float* kbase = qbase + (size_t)C * L;
   const float* vbase = kbase + (size_t)C * L;
@@ -189,8 +190,9 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_bwd_dkv_kernel(const float* _
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
-  const int kblk0 = blockIdx.x * (64 * NK) + wave * (16 * NK);
+  const TileId tile = xcd_tile();
+  const int head = tile.head, b = tile.b, heads = gridDim.y;
+  const int kblk0 = tile.x * (64 * NK) + wave * (16 * NK);
   const float* qbase = qkv + ((size_t)b * 3 * C + (size_t)head * D) * L;
   const float* kbase = qbase + (size_t)C * L;
   const float* vbase = kbase + (size_t)C * L;

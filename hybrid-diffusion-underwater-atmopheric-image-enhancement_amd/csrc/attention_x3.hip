@@ -82,8 +82,9 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3_kernel(const floa
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int qblk0 = blockIdx.x * QB + wave * (16 * NQ);
+  const TileId tile = xcd_tile();
+  const int head = tile.head, b = tile.b;
+  const int qblk0 = tile.x * QB + wave * (16 * NQ);
   const float* qbase = qkv + ((size_t)b * 3 * C + (size_t)head * D) * L;
   const float* kbase = qbase + (size_t)C * L;
   const float* vbase = kbase + (size_t)C * L;

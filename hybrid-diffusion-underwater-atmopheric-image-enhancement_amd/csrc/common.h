@@ -41,6 +41,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// XCD-aware tile order for grids of (blocks along the sequence, heads, batch).  Workgroups are handed to the 8 XCDs round
+// robin by linear id, and each XCD has its own L2: with the plain order the 8 XCDs all stream the K/V (or Q/dO) of every
+// head (measured on the forward: 4.5x the algorithmic HBM bytes).  This bijection gives each (head, sample) pair to ONE XCD
+// -- pair p runs on XCD p % 8 -- so its operands are fetched into one L2 only.  Needs heads * batch % 8 == 0 (heads = 8 in
+// this model); otherwise the identity.
+struct TileId { int x, head, b; };
+__device__ __forceinline__ TileId xcd_tile() {
+  const unsigned gx = gridDim.x, pairs = gridDim.y * gridDim.z;
+  if (pairs % 8u != 0u) return TileId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  const unsigned lin = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned xcd = lin & 7u, idx = lin >> 3;
+  const unsigned pair = (idx / gx) * 8u + xcd, x = idx % gx;
+  return TileId{(int)x, (int)(pair % gridDim.y), (int)(pair / gridDim.y)};
+}
+
 int contraction_mode();   // HDIFF_CONTRACT_*
 // attention_x3.hip: returns false when the shape is not covered (caller falls back to the fp32 kernels)
 bool launch_mha_fwd_x3(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, hipStream_t stream);
