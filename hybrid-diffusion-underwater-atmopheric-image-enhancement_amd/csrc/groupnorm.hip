@@ -6,8 +6,8 @@
 //
 // The input may be the virtual channel concat of two tensors (skip connections, ModelCondition.py:271); a group may
 // straddle the seam (384 channels / 32 groups = 12 per group, seam at 256), so sources are chosen per channel.
-// Each (sample, group) is split over `nsplit` workgroups; every workgroup produces (count, mean, M2) of its slice with a
-// local two-pass (the second pass re-reads its own slice from L2), and the partials are merged with Chan's formula.
+// Each (sample, group) is split over `nsplit` workgroups; every workgroup produces (count, mean, M2) of its slice in one
+// pass over shifted data, and the partials are merged with Chan's formula.
 #include "common.h"
 
 using namespace hdiff;
@@ -43,7 +43,15 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __res
   const int cnt_units = max(0, hi - lo);
   const float count = (float)cnt_units * (vec ? 4.f : 1.f) * (float)cpg;
 
-  float s = 0.f;
+  // ONE pass: sums of d = x - K and of d^2 with K = the slice's first element (a value near the mean keeps the
+  // subtraction mean^2 - mean(x^2)-style cancellation out of fp32: d is O(std), so M2 = S2 - S1^2/n loses nothing)
+  float K = 0.f;
+  if (cnt_units > 0) {
+    const int c = g * cpg;
+    const float* plane = (c < C0) ? x0 + ((size_t)b * C0 + c) * HW : x1 + ((size_t)b * C1 + (c - C0)) * HW;
+    K = plane[vec ? 4 * lo : lo];
+  }
+  float s1 = 0.f, s2 = 0.f;
   for (int cc = 0; cc < cpg; ++cc) {
     const int c = g * cpg + cc;
     const float* plane = (c < C0) ? x0 + ((size_t)b * C0 + c) * HW : x1 + ((size_t)b * C1 + (c - C0)) * HW;
@@ -51,33 +59,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __res
       const float4* p4 = reinterpret_cast<const float4*>(plane);
       for (int i = lo + threadIdx.x; i < hi; i += GN_THREADS) {
         const float4 v = p4[i];
-        s += (v.x + v.y) + (v.z + v.w);
-      }
-    } else {
-      for (int i = lo + threadIdx.x; i < hi; i += GN_THREADS) s += plane[i];
-    }
-  }
-  const float mean = (count > 0.f) ? block_sum(s, red) / count : 0.f;
-
-  float m2 = 0.f;
-  for (int cc = 0; cc < cpg; ++cc) {
-    const int c = g * cpg + cc;
-    const float* plane = (c < C0) ? x0 + ((size_t)b * C0 + c) * HW : x1 + ((size_t)b * C1 + (c - C0)) * HW;
-    if (vec) {
-      const float4* p4 = reinterpret_cast<const float4*>(plane);
-      for (int i = lo + threadIdx.x; i < hi; i += GN_THREADS) {
-        const float4 v = p4[i];
-        const float a = v.x - mean, bb = v.y - mean, cq = v.z - mean, d = v.w - mean;
-        m2 += (a * a + bb * bb) + (cq * cq + d * d);
+        const float a = v.x - K, bb = v.y - K, cq = v.z - K, d = v.w - K;
+        s1 += (a + bb) + (cq + d);
+        s2 += (a * a + bb * bb) + (cq * cq + d * d);
       }
     } else {
       for (int i = lo + threadIdx.x; i < hi; i += GN_THREADS) {
-        const float a = plane[i] - mean;
-        m2 += a * a;
+        const float a = plane[i] - K;
+        s1 += a;
+        s2 += a * a;
       }
     }
   }
-  m2 = block_sum(m2, red);
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  const float mean = (count > 0.f) ? K + s1 / count : 0.f;
+  const float m2 = (count > 0.f) ? fmaxf(s2 - s1 * s1 / count, 0.f) : 0.f;
   if (threadIdx.x == 0) {
     float* o = ws + ((size_t)bg * nsplit + split) * 3;
     o[0] = count;
