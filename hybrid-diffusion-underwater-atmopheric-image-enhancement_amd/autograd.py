@@ -112,12 +112,12 @@ def _plane_sums(dy, want_vec: bool, want_bias: bool):
     lib = _capi.lib()
     B, Cc = int(dy.shape[0]), int(dy.shape[1])
     HW = dy.numel() // (B * Cc)
-    dvec = torch.empty(B, Cc, device=dy.device) if want_vec else None
+    dvec = torch.empty(B, Cc, device=dy.device) if (want_vec or want_bias) else None   # also the scratch of the bias sum
     dbias = torch.empty(Cc, device=dy.device) if want_bias else None
     if want_vec or want_bias:
         _capi.check(lib.hdiff_bias_addvec_grad(dy.data_ptr(), B, Cc, HW, _p(dvec), _p(dbias), _stream(dy.device)),
                     "bias_addvec_grad")
-    return dvec, dbias
+    return (dvec if want_vec else None), dbias
 
 
 # ----------------------------------------------------------------------------------------------------------------------

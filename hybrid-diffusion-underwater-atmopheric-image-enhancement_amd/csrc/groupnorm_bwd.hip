@@ -122,6 +122,34 @@ __global__ __launch_bounds__(T) void bias_addvec_grad_kernel(const float* __rest
   if (threadIdx.x == 0 && dbias) dbias[c] = total;
 }
 
+// The same sums with one workgroup per (channel, sample) plane and 16-byte loads (the single-kernel form above walks the
+// batch inside C workgroups: 1.2 TB/s at C = 128); dbias is then a fixed-order sum over the batch of the per-sample sums.
+__global__ __launch_bounds__(T) void plane_sum_kernel(const float* __restrict__ dy, int C, int HW, float* __restrict__ dvec) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* p = dy + ((size_t)b * C + c) * HW;
+  float s = 0.f;
+  if ((HW & 3) == 0) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    for (int i = threadIdx.x; i < (HW >> 2); i += T) {
+      const float4 v = p4[i];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += T) s += p[i];
+  }
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) dvec[b * C + c] = s;
+}
+
+__global__ void batch_sum_kernel(const float* __restrict__ dvec, int B, int C, float* __restrict__ dbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (int b = 0; b < B; ++b) t += dvec[b * C + c];
+  dbias[c] = t;
+}
+
 }  // namespace
 
 extern "C" int hdiff_gn_swish_bwd(const float* x0, const float* x1, int C0, int C1, int B, int HW, int G, const float* dA,
@@ -153,7 +181,13 @@ extern "C" int hdiff_bias_addvec_grad(const float* dy, int B, int C, int HW, flo
                                       hdiff_stream_t stream) {
   HDIFF_CHECK_ARG(dy && (dvec || dbias), "bias_addvec_grad: null pointer");
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  hipLaunchKernelGGL(bias_addvec_grad_kernel, dim3(C), dim3(T), 0, (hipStream_t)stream, dy, B, C, HW, dvec, dbias);
+  if (dvec != nullptr) {
+    hipLaunchKernelGGL(plane_sum_kernel, dim3(C, B), dim3(T), 0, (hipStream_t)stream, dy, C, HW, dvec);
+    if (dbias != nullptr)
+      hipLaunchKernelGGL(batch_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dvec, B, C, dbias);
+  } else {
+    hipLaunchKernelGGL(bias_addvec_grad_kernel, dim3(C), dim3(T), 0, (hipStream_t)stream, dy, B, C, HW, dvec, dbias);
+  }
   HDIFF_CHECK_LAUNCH("bias_addvec_grad_kernel");
   return HDIFF_OK;
 }
