@@ -36,6 +36,28 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def _gpu_input(x, name):
+    """A caller's tensor as the kernels need it: on the GPU (no CPU fallback), fp32 / integer, contiguous NCHW."""
+    if x.is_cuda and not x.is_contiguous():
+        x = x.contiguous()              # the reference accepts strided views; the kernels read dense NCHW
+    E.require_gpu_tensor(x, name)
+    return x
+
+
+def _timesteps(t, T: int, device):
+    """The index vector of ``extract`` (reference :9-16) as the kernels read it: int64, contiguous, on ``device``, and in
+    range -- ``torch.gather`` raises for an index outside [0, T), so does this (the kernels clamp on top: a bad index can
+    never fault the GPU)."""
+    if not torch.is_tensor(t) or t.dtype not in (torch.int64, torch.int32):
+        raise RuntimeError("gather(): Expected dtype int64 for index")
+    t = t.to(device=device, dtype=torch.int64).contiguous()
+    if t.numel():
+        lo, hi = torch.stack([t.min(), t.max()]).tolist()
+        if lo < 0 or hi >= T:
+            raise RuntimeError(f"index {hi if hi >= T else lo} is out of bounds for dimension 0 with size {T}")
+    return t
+
+
 class GaussianDiffusionTrainer(nn.Module):
     """forward(x_0, labels) -> unreduced squared error of the eps prediction (reference :19-46)."""
 
@@ -51,28 +73,29 @@ class GaussianDiffusionTrainer(nn.Module):
     def forward(self, x_0, labels, *, t=None, noise=None):
         """``t`` / ``noise`` may be injected (parity tests); by default they are drawn exactly where the reference
         draws them (``torch.randint`` then ``torch.randn_like``, reference :41-42)."""
-        E.require_gpu_tensor(x_0, "x_0")
-        E.require_gpu_tensor(labels, "labels")
+        x_0, labels = _gpu_input(x_0, "x_0"), _gpu_input(labels, "labels")
         lib = _capi.lib()
         B = int(x_0.shape[0])
         if t is None:
             t = torch.randint(self.T, size=(B,), device=x_0.device)
-        t = t.to(device=x_0.device, dtype=torch.int64).contiguous()      # the gather kernels read int64 indices
+        t = _timesteps(t, self.T, x_0.device)
         if noise is None:
             noise = torch.randn_like(x_0)
-        E.require_gpu_tensor(noise, "noise")
+        noise = _gpu_input(noise, "noise")
+        assert noise.shape == x_0.shape
         sa, sb = self.sqrt_alphas_bar.float(), self.sqrt_one_minus_alphas_bar.float()
         x_t = torch.empty_like(x_0)
-        s = _stream(x_0.device)
-        _capi.check(lib.hdiff_q_sample(x_0.data_ptr(), noise.data_ptr(), t.data_ptr(), sa.data_ptr(), sb.data_ptr(),
-                                       x_t.data_ptr(), B, x_0.numel() // B, s), "q_sample")
-        eps_hat = self.model(x_t, t, labels)
-        if eps_hat.requires_grad:
-            from ..autograd import sq_err_with_grad
-            return sq_err_with_grad(eps_hat, noise)
-        loss = torch.empty_like(x_0)
-        _capi.check(lib.hdiff_sq_err(eps_hat.data_ptr(), noise.data_ptr(), loss.data_ptr(), x_0.numel(), s), "sq_err")
-        return loss
+        with torch.cuda.device(x_0.device):
+            s = _stream(x_0.device)
+            _capi.check(lib.hdiff_q_sample(x_0.data_ptr(), noise.data_ptr(), t.data_ptr(), sa.data_ptr(), sb.data_ptr(),
+                                           x_t.data_ptr(), B, x_0.numel() // B, self.T, s), "q_sample")
+            eps_hat = self.model(x_t, t, labels)
+            if eps_hat.requires_grad:
+                from ..autograd import sq_err_with_grad
+                return sq_err_with_grad(eps_hat, noise)
+            loss = torch.empty_like(x_0)
+            _capi.check(lib.hdiff_sq_err(eps_hat.data_ptr(), noise.data_ptr(), loss.data_ptr(), x_0.numel(), s), "sq_err")
+            return loss
 
 
 class _SamplerPlan:
@@ -114,7 +137,10 @@ class _SamplerPlan:
         return p
 
     def variant(self, inject_noise: bool, seed: int) -> E.Plan:
-        key = (inject_noise, seed if not inject_noise else 0, _capi.lib().hdiff_get_contraction_mode())
+        # the guidance weight is a launch argument of the fused update: the reference reads self.w on every step (:78), so
+        # a changed sampler.w must rebuild the captured step
+        key = (inject_noise, seed if not inject_noise else 0, _capi.lib().hdiff_get_contraction_mode(),
+               float(self._sampler.w))
         if key not in self._variants:
             self.seed = seed
             self._variants.clear()          # a graph bakes its seed (and the contraction mode): keep one live variant
@@ -143,15 +169,18 @@ class GaussianDiffusionSampler(nn.Module):
     # -- single-step API of the reference -----------------------------------------------------------------------------
     def predict_xt_prev_mean_from_eps(self, x_t, t, eps):
         assert x_t.shape == eps.shape
-        E.require_gpu_tensor(x_t, "x_t")
+        x_t, eps = _gpu_input(x_t, "x_t"), _gpu_input(eps, "eps")
+        t = _timesteps(t, self.T, x_t.device)
         lib = _capi.lib()
         B = int(x_t.shape[0])
         c1 = self.coeff1.float()
         neg_c2 = -(self.coeff2.float())
         out = torch.empty_like(x_t)
         # coeff1[t]*x_t - coeff2[t]*eps  ==  coeff1[t]*x_t + (-coeff2[t])*eps with identical roundings
-        _capi.check(lib.hdiff_q_sample(x_t.data_ptr(), eps.data_ptr(), t.data_ptr(), c1.data_ptr(), neg_c2.data_ptr(),
-                                       out.data_ptr(), B, x_t.numel() // B, _stream(x_t.device)), "posterior_mean")
+        with torch.cuda.device(x_t.device):
+            _capi.check(lib.hdiff_q_sample(x_t.data_ptr(), eps.data_ptr(), t.data_ptr(), c1.data_ptr(), neg_c2.data_ptr(),
+                                           out.data_ptr(), B, x_t.numel() // B, self.T, _stream(x_t.device)),
+                        "posterior_mean")
         return out
 
     def _paired_eps(self, x_t, t, labels):
@@ -164,22 +193,28 @@ class GaussianDiffusionSampler(nn.Module):
         return e2[:B], e2[B:]
 
     def p_mean_variance(self, x_t, t, labels):
+        x_t, labels = _gpu_input(x_t, "x_t"), _gpu_input(labels, "labels")
+        t = _timesteps(t, self.T, x_t.device)
         var = torch.cat([self.posterior_var[1:2], self.betas[1:]])
         var = extract(var, t, x_t.shape)
         eps_c, eps_u = self._paired_eps(x_t, t, labels)
         lib = _capi.lib()
         eps = torch.empty_like(x_t)
-        _capi.check(lib.hdiff_axpby(C.c_float(1. + self.w), eps_c.contiguous().data_ptr(), C.c_float(-self.w),
-                                    eps_u.contiguous().data_ptr(), eps.data_ptr(), x_t.numel(), _stream(x_t.device)),
-                    "cfg_combine")
+        with torch.cuda.device(x_t.device):
+            _capi.check(lib.hdiff_axpby(C.c_float(1. + self.w), eps_c.contiguous().data_ptr(), C.c_float(-self.w),
+                                        eps_u.contiguous().data_ptr(), eps.data_ptr(), x_t.numel(), _stream(x_t.device)),
+                        "cfg_combine")
         return self.predict_xt_prev_mean_from_eps(x_t, t, eps=eps), var
 
     # -- the loop -----------------------------------------------------------------------------------------------------
     def forward(self, x_T, labels, *, noise_by_step=None, trajectory: Optional[List[torch.Tensor]] = None):
         """``noise_by_step[time_step]`` injects the per-step z (parity tests); ``trajectory`` collects the pre-clip
         x_t after every step.  Both default to the reference behaviour."""
-        E.require_gpu_tensor(x_T, "x_T")
-        E.require_gpu_tensor(labels, "labels")
+        x_T, labels = _gpu_input(x_T, "x_T"), _gpu_input(labels, "labels")
+        with torch.cuda.device(x_T.device):
+            return self._forward(x_T, labels, noise_by_step, trajectory)
+
+    def _forward(self, x_T, labels, noise_by_step, trajectory):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
             # the reference would build an autograd graph through T steps; sampling is an inference loop here
             raise RuntimeError("GaussianDiffusionSampler.forward must run under torch.no_grad() (as TrainCondition.eval does)")
@@ -191,7 +226,9 @@ class GaussianDiffusionSampler(nn.Module):
         if sp is None or sp.unet is not self.model.plan_for(2 * B, H, W, dev):
             sp = _SamplerPlan(self, B, H, W, dev)
             self._splans = {key: sp}
-        self.model.plan_for(2 * B, H, W, dev)                       # repack weights if they changed
+        # One pack per call is nothing against T steps, and it closes the one hole of version-keyed staleness: a write through
+        # ``p.data`` (EMA swaps, ``dist.broadcast(p.data)``) does not bump ``p._version``.
+        sp.unet.plan.pack_weights()
         self.model.check_indices(torch.zeros_like(labels), labels)
         inject = noise_by_step is not None
         seed = 0 if inject else int(torch.empty((), dtype=torch.int64).random_().item())

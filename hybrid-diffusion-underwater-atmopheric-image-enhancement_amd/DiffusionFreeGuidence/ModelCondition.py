@@ -24,9 +24,18 @@ def _params_of(mod: nn.Module, prefix: str = "") -> Dict[str, torch.Tensor]:
     return {prefix + k: v for k, v in mod.state_dict(keep_vars=True).items()}
 
 
-def _check_inputs(**tensors: torch.Tensor) -> None:
+def _inputs(**tensors: torch.Tensor):
+    """The caller's tensors as the kernels need them: on the GPU (there is no CPU fallback), dense NCHW (a strided view is
+    copied, as ATen would do internally), indices as int64 (nn.Embedding also takes int32)."""
+    out = []
     for name, t in tensors.items():
+        if t.is_cuda and not t.is_contiguous():
+            t = t.contiguous()
         E.require_gpu_tensor(t, name)
+        if t.dtype == torch.int32:
+            t = t.to(torch.int64)
+        out.append(t)
+    return out[0] if len(out) == 1 else tuple(out)
 
 
 class _EagerMixin:
@@ -43,7 +52,7 @@ class Swish(nn.Module):
     """x * sigmoid(x) (reference ModelCondition.py:22-24).  Inside the UNet it is fused into the consuming kernels."""
 
     def forward(self, x):
-        _check_inputs(x=x)
+        x = _inputs(x=x)
         plan = E.Plan(x.device)
         n = x.numel()
         one = torch.ones(1, device=x.device)
@@ -71,7 +80,7 @@ class TimeEmbedding(nn.Module, _EagerMixin):
         )
 
     def forward(self, t):
-        _check_inputs(t=t)
+        t = _inputs(t=t)
         plan = E.Plan(t.device)
         out = E.emit_embed_mlp(plan, _params_of(self.timembedding, "e."), "e", t, int(t.shape[0]))
         return self._finish(plan, out)
@@ -91,7 +100,7 @@ class ConditionalEmbedding(nn.Module, _EagerMixin):
         )
 
     def forward(self, t):
-        _check_inputs(labels=t)
+        t = _inputs(labels=t)
         plan = E.Plan(t.device)
         out = E.emit_embed_mlp(plan, _params_of(self.condEmbedding, "e."), "e", t, int(t.shape[0]))
         return self._finish(plan, out)
@@ -106,7 +115,7 @@ class DownSample(nn.Module, _EagerMixin):
         self.c2 = nn.Conv2d(in_ch, in_ch, 5, stride=2, padding=2)
 
     def forward(self, x, temb, cemb):
-        _check_inputs(x=x)
+        x = _inputs(x=x)
         B, Cc, H, W = (int(v) for v in x.shape)
         plan = E.Plan(x.device)
         return self._finish(plan, E.emit_downsample(plan, _params_of(self, "m."), "m", x, B, Cc, H, W))
@@ -121,7 +130,7 @@ class UpSample(nn.Module, _EagerMixin):
         self.t = nn.ConvTranspose2d(in_ch, in_ch, 5, 2, 2, 1)
 
     def forward(self, x, temb, cemb):
-        _check_inputs(x=x)
+        x = _inputs(x=x)
         B, Cc, H, W = (int(v) for v in x.shape)
         plan = E.Plan(x.device)
         return self._finish(plan, E.emit_upsample(plan, _params_of(self, "m."), "m", x, B, Cc, H, W))
@@ -143,8 +152,14 @@ class ResBlock(nn.Module, _EagerMixin):
         self.out_ch = out_ch
 
     def forward(self, x, temb, cemb=None):
-        _check_inputs(x=x, temb=temb)
-        _refuse_dropout(self)
+        x, temb = _inputs(x=x, temb=temb)
+        if cemb is not None:
+            cemb = _inputs(cemb=cemb)
+        if _dropout_active(self):
+            # nn.Dropout in train mode runs whether or not autograd records (ModelCondition.py:185): the eager launch path
+            # carries the dropout kernels (keep-mask from torch's generator), the static plan does not
+            from ..autograd import res_block
+            return res_block(self, x, None, temb, cemb, True)
         B, _, H, W = (int(v) for v in x.shape)
         plan = E.Plan(x.device)
         has_attn = isinstance(self.attn, nn.MultiheadAttention)
@@ -152,11 +167,8 @@ class ResBlock(nn.Module, _EagerMixin):
         return self._finish(plan, out)
 
 
-def _refuse_dropout(mod: nn.Module) -> None:
-    for m in mod.modules():
-        if isinstance(m, nn.Dropout) and m.training and m.p > 0:
-            raise NotImplementedError("hdiff: train-mode dropout (p > 0) is not built yet on the HIP path; call .eval() "
-                                      "or construct the model with dropout=0")
+def _dropout_active(mod: nn.Module) -> bool:
+    return any(isinstance(m, nn.Dropout) and m.training and m.p > 0 for m in mod.modules())
 
 
 class UNet(nn.Module):
@@ -204,6 +216,12 @@ class UNet(nn.Module):
         ps = list(self.parameters())
         return tuple(p.data_ptr() for p in ps), tuple(p._version for p in ps)
 
+    def invalidate_packed(self) -> None:
+        """Force a repack on the next forward.  Needed only after a write that bypasses autograd's version counter
+        (``p.data.copy_``, ``dist.broadcast(p.data)``); ``p.copy_`` under ``no_grad``, optimizer steps and
+        ``load_state_dict`` are seen automatically, and ``GaussianDiffusionSampler.forward`` repacks on every call."""
+        self._packed_versions.clear()
+
     def plan_for(self, B: int, H: int, W: int, device) -> E.UNetPlan:
         """Launch plan for (B, H, W) with up-to-date packed weights (repacked whenever a parameter changed)."""
         ptrs, versions = self._param_signature()
@@ -233,18 +251,21 @@ class UNet(nn.Module):
             raise IndexError("index out of range in self")
 
     def forward(self, x, t, labels):
-        _check_inputs(x=x, t=t, labels=labels)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            from ..autograd import unet_forward_with_grad
-            return unet_forward_with_grad(self, x, t, labels)
-        _refuse_dropout(self)
+        x, t, labels = _inputs(x=x, t=t, labels=labels)
         B, Cx, H, W = (int(v) for v in x.shape)
         if Cx != 3:
             raise RuntimeError(f"expected input[{B}, {Cx}, {H}, {W}] to have 3 channels")
-        self.check_indices(t, labels)
-        up = self.plan_for(B, H, W, x.device)
-        up.x.copy_(x)
-        up.t.copy_(t)
-        up.labels.copy_(labels)
-        up.plan.run()
-        return up.out.clone()
+        with torch.cuda.device(x.device):
+            records = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+            if records or _dropout_active(self):
+                # training, or train-mode dropout under no_grad (the reference applies nn.Dropout there too,
+                # ModelCondition.py:185): eager launches through the autograd Functions, which carry the dropout kernels
+                from ..autograd import unet_forward_with_grad
+                return unet_forward_with_grad(self, x, t, labels)
+            self.check_indices(t, labels)
+            up = self.plan_for(B, H, W, x.device)
+            up.x.copy_(x)
+            up.t.copy_(t)
+            up.labels.copy_(labels)
+            up.plan.run()
+            return up.out.clone()

@@ -61,8 +61,9 @@ _PROTOS = {
     "hdiff_gn_swish_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p]),
     "hdiff_mha_flash_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "hdiff_mha_flash_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                      C.c_int, C.c_int, C.c_void_p]),
+    "hdiff_mha_flash_bwd_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "hdiff_mha_flash_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hdiff_conv2d_wgrad_workspace": (C.c_int, [C.POINTER(WgradDesc), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "hdiff_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p, C.c_int, C.c_void_p]),
     "hdiff_conv_wgrad_unpack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -79,7 +80,7 @@ _PROTOS = {
     "hdiff_linear_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hdiff_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                 C.c_void_p]),
+                                 C.c_int, C.c_void_p]),
     "hdiff_sq_err": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hdiff_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_double, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -341,8 +341,12 @@ class _FlashFn(Function):
         Cc, L = C3 // 3, H * W
         delta = torch.empty(B, NUM_HEADS, L, device=qkv.device)
         dqkv = torch.empty_like(qkv)
+        need = C.c_int64(0)
+        _capi.check(lib.hdiff_mha_flash_bwd_workspace(B, Cc, NUM_HEADS, L, C.byref(need)), "mha_flash_bwd_workspace")
+        ws = torch.empty(need.value, dtype=torch.float32, device=qkv.device) if need.value else None   # dQ partial slabs
         _capi.check(lib.hdiff_mha_flash_bwd(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                            dqkv.data_ptr(), B, Cc, NUM_HEADS, L, _stream(qkv.device)), "mha_flash_bwd")
+                                            dqkv.data_ptr(), _p(ws), B, Cc, NUM_HEADS, L, _stream(qkv.device)),
+                    "mha_flash_bwd")
         return dqkv
 
 

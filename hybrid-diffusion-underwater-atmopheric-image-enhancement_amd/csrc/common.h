@@ -41,6 +41,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute is per DEVICE: true the first time the calling site (one `static uint64_t` mask each) runs with the
+// current device, so that a process using several GPUs raises the dynamic-LDS limit on each of them.
+static inline bool first_use_on_device(uint64_t& mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  const uint64_t bit = 1ull << dev;
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 // XCD-aware tile order for grids of (blocks along the sequence, heads, batch).  Workgroups are handed to the 8 XCDs round
 // robin by linear id, and each XCD has its own L2: with the plain order the 8 XCDs all stream the K/V (or Q/dO) of every
 // head (measured on the forward: 4.5x the algorithmic HBM bytes).  This bijection gives each (head, sample) pair to ONE XCD

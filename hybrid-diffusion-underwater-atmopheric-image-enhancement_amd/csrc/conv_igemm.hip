@@ -317,11 +317,10 @@ int ceil_log2(int v) {
 
 template <int WN, int CK, int NXS, int NWS, int SPEC, bool TWOM>
 void launch_t(const ConvK& k, dim3 grid, size_t lds_bytes, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static uint64_t attr_mask = 0;
+  if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WN, CK, NXS, NWS, SPEC, TWOM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_igemm_kernel<WN, CK, NXS, NWS, SPEC, TWOM>), grid, dim3(NTHREADS), lds_bytes, stream, k);
 }

@@ -332,12 +332,11 @@ extern "C" int hdiff_conv2d_wgrad(const hdiff_conv_wgrad_desc* d, float* dwp, in
   const size_t lds = (size_t)(BM * DYROW + k.CKW * k.PLANE + 2 * k.CKW) * sizeof(float);
   HDIFF_CHECK_ARG(lds <= 160 * 1024, "conv2d_wgrad: tile needs %zu bytes of LDS", lds);
 
-  static bool attr_set = false;
-  if (!attr_set) {
+  static uint64_t attr_mask = 0;
+  if (first_use_on_device(attr_mask)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   dim3 grid(cdiv(d->Cout, BM), cdiv(d->CinPad, k.CKW), nsplit);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread

@@ -19,7 +19,8 @@ inline int grid_for(int64_t n, int per_thread = 1) {
 // Diffusion.py:259-263 with eta = 0:
 //   y0 = (y - eps * sqrt(1 - at)) / sqrt(at) ;  y' = sqrt(at_next) * y0 + c2 * eps        (c1 * randn = 0 is dropped: x + 0 = x)
 // tab[k] = {sqrt(1 - at), sqrt(at), sqrt(at_next), c2} of DDIM step k, formed on the host with the reference's fp32 ops.
-__global__ void ddim_step_kernel(const float* __restrict__ y, const float* __restrict__ eps, float* __restrict__ y_next,
+// y and y_next may be the same buffer (the sampler updates in place): neither is __restrict__.
+__global__ void ddim_step_kernel(const float* y, const float* __restrict__ eps, float* y_next,
                                  const float* __restrict__ tab, const int32_t* __restrict__ step_ptr,
                                  int32_t* __restrict__ nan_flag, int64_t n) {
   const int k = *step_ptr;

@@ -122,11 +122,11 @@ __global__ void gn_finalize_kernel(const float* __restrict__ ws, int B, int C, i
 
 __global__ void gn_swish_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                       const float* __restrict__ shift, float* __restrict__ y, int HW) {
-  const int bc = blockIdx.y;
+  const int bc = blockIdx.x;   // plane index on x: B*C may exceed 65 535
   const float sc = scale[bc], sh = shift[bc];
   const float* xp = x + (size_t)bc * HW;
   float* yp = y + (size_t)bc * HW;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x)
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x)
     yp[i] = swishf(fmaf(xp[i], sc, sh));
 }
 
@@ -163,7 +163,7 @@ extern "C" int hdiff_gn_swish_apply(const float* x, const float* scale, const fl
   HDIFF_CHECK_ARG(x && scale && shift && y, "gn_swish_apply: null pointer");
   const int bx = cdiv(HW, 256) < 64 ? cdiv(HW, 256) : 64;
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  hipLaunchKernelGGL(gn_swish_apply_kernel, dim3(bx, B * C), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, HW);
+  hipLaunchKernelGGL(gn_swish_apply_kernel, dim3(B * C, bx), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, HW);
   HDIFF_CHECK_LAUNCH("gn_swish_apply_kernel");
   return HDIFF_OK;
 }

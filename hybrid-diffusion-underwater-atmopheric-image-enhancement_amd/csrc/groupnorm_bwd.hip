@@ -90,7 +90,7 @@ __global__ __launch_bounds__(T) void gn_bwd_apply_kernel(const float* __restrict
                                                          const float* __restrict__ gs1, const float* __restrict__ gs2,
                                                          float* __restrict__ dx0, float* __restrict__ dx1) {
   const int C = C0 + C1, cpg = C / G;
-  const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+  const int bc = blockIdx.x, b = bc / C, c = bc - b * C;   // plane index on x: B*C may exceed 65 535
   const int g = c / cpg;
   const float mu = mean[b * G + g], rs = rstd[b * G + g], ga = gamma[c], be = beta[c];
   const float inv_n = 1.0f / ((float)cpg * (float)HW);
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(T) void gn_bwd_apply_kernel(const float* __restrict
   const float* xp = (c < C0) ? x0 + ((size_t)b * C0 + c) * HW : x1 + ((size_t)b * C1 + (c - C0)) * HW;
   float* op = (c < C0) ? dx0 + ((size_t)b * C0 + c) * HW : dx1 + ((size_t)b * C1 + (c - C0)) * HW;
   const float* dp = dA + (size_t)bc * HW;
-  for (int i = blockIdx.x * T + threadIdx.x; i < HW; i += gridDim.x * T) {
+  for (int i = blockIdx.y * T + threadIdx.x; i < HW; i += gridDim.y * T) {
     const float xh = (xp[i] - mu) * rs;
     const float dy = dswish_times(dp[i], fmaf(xh, ga, be));
     op[i] = rs * (ga * dy - m1 - xh * m2);
@@ -171,7 +171,7 @@ extern "C" int hdiff_gn_swish_bwd(const float* x0, const float* x1, int C0, int 
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p1, p2, gamma, B, C, G, gs1, gs2, dgamma,
                      dbeta);
   const int bx = cdiv(HW, T) < 32 ? cdiv(HW, T) : 32;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bx, B * C), dim3(T), 0, s, x0, x1, C0, C1, HW, G, dA, mean, rstd, gamma, beta,
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C, bx), dim3(T), 0, s, x0, x1, C0, C1, HW, G, dA, mean, rstd, gamma, beta,
                      gs1, gs2, dx0, dx1);
   HDIFF_CHECK_LAUNCH("gn_swish_bwd kernels");
   return HDIFF_OK;

@@ -99,9 +99,11 @@ __global__ void randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
                                 const int64_t* __restrict__ t, const float* __restrict__ sa,
-                                const float* __restrict__ sb, float* __restrict__ xt, int per_sample) {
+                                const float* __restrict__ sb, float* __restrict__ xt, int per_sample, int T) {
   const int b = blockIdx.y;
-  const float a = sa[t[b]], c = sb[t[b]];
+  int64_t tb = t[b];
+  tb = tb < 0 ? 0 : (tb >= T ? T - 1 : tb);     // never fault on a bad index; the host validates (extract raises)
+  const float a = sa[tb], c = sb[tb];
   const size_t base = (size_t)b * per_sample;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += gridDim.x * blockDim.x)
     xt[base + i] = a * x0[base + i] + c * noise[base + i];   // mul, mul, add: the reference's roundings (contraction is off)
@@ -118,9 +120,10 @@ __global__ void sq_err_kernel(const float* __restrict__ a, const float* __restri
 // x_next = coeff1[t]*x - coeff2[t]*((1+w)*eps_c - w*eps_u) + sigma[t]*z   (DiffusionCondition.py:78-79, 95)
 // Written with separate multiplies/adds in the reference's order (no fma contraction across terms) so that the CPU
 // oracle and this kernel round identically given identical eps.
-__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_c,
+// x and x_next may be the same buffer (the sampler updates in place): neither is __restrict__.
+__global__ void ddpm_step_kernel(const float* x, const float* __restrict__ eps_c,
                                  const float* __restrict__ eps_u, const float* __restrict__ noise,
-                                 float* __restrict__ x_next, const float* __restrict__ coeff1,
+                                 float* x_next, const float* __restrict__ coeff1,
                                  const float* __restrict__ coeff2, const float* __restrict__ sigma,
                                  const int32_t* __restrict__ step_ptr, float w1, float w, uint64_t seed,
                                  int32_t* __restrict__ nan_flag, int64_t n) {
@@ -277,12 +280,13 @@ int hdiff_linear_rows(const float* x, const int64_t* idx, int n_rows, const floa
 }
 
 int hdiff_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ab, const float* sqrt_1mab,
-                   float* xt, int B, int per_sample, hdiff_stream_t stream) {
+                   float* xt, int B, int per_sample, int T, hdiff_stream_t stream) {
   HDIFF_CHECK_ARG(x0 && noise && t && sqrt_ab && sqrt_1mab && xt, "q_sample: null pointer");
+  HDIFF_CHECK_ARG(B > 0 && B <= 65535 && per_sample > 0 && T > 0, "q_sample: bad sizes B=%d per_sample=%d T=%d", B, per_sample, T);
   const int bx = cdiv(per_sample, 256) < 256 ? cdiv(per_sample, 256) : 256;
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   hipLaunchKernelGGL(q_sample_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, x0, noise, t, sqrt_ab, sqrt_1mab,
-                     xt, per_sample);
+                     xt, per_sample, T);
   HDIFF_CHECK_LAUNCH("q_sample_kernel");
   return HDIFF_OK;
 }

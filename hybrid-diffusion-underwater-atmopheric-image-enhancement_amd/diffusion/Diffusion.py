@@ -137,6 +137,8 @@ class GaussianDiffusionSampler(nn.Module):
         """``y_T`` / ``noise_by_step`` inject the random draws (parity runs; ``noise_by_step[k]`` is the k-th per-step draw of
         the ancestral loop, in call order); by default they come from torch's generator exactly where the reference draws
         them.  ``trajectory`` collects the pre-clip y_t after every step."""
+        if input_image.is_cuda and not input_image.is_contiguous():
+            input_image = input_image.contiguous()
         E.require_gpu_tensor(input_image, "input_image")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
             raise RuntimeError("GaussianDiffusionSampler.forward must run under torch.no_grad()")
@@ -155,7 +157,7 @@ class GaussianDiffusionSampler(nn.Module):
         if sp is None or sp.unet is not self.model.plan_for(B, H, W, dev, True):
             sp = _StepPlan(self, B, H, W, dev, int(ddim_step) if ddim else None, inject, seed)
             self._plans = {key: sp}                                  # a graph bakes its seed and contraction mode: keep one live plan
-        self.model.plan_for(B, H, W, dev, True)                     # repack weights if they changed
+        sp.unet.plan.pack_weights()     # once per call: also catches writes through p.data, which p._version does not see
         self.model.dynamic_forward(torch.cat([img, img], dim=1))    # the reference runs it on every call (requires_grad only)
         y = torch.randn_like(img) if y_T is None else y_T            # :226 / :239
         up = sp.unet

@@ -16,8 +16,8 @@ from torch import nn
 from torch.nn import init
 
 from .. import engine as E
-from ..DiffusionFreeGuidence.ModelCondition import (DownSample, Swish, TimeEmbedding, UpSample, _check_inputs, _EagerMixin,
-                                                    _params_of, _refuse_dropout)
+from ..DiffusionFreeGuidence.ModelCondition import (DownSample, Swish, TimeEmbedding, UpSample, _dropout_active, _EagerMixin,
+                                                    _inputs, _params_of)
 
 __all__ = ["Swish", "TimeEmbedding", "ConditionalEmbedding", "DownSample", "UpSample", "ResBlock", "DynamicUNet"]
 
@@ -38,7 +38,7 @@ class ConditionalEmbedding(nn.Module, _EagerMixin):
         self.linear2 = nn.Linear(dim, dim)
 
     def forward(self, label_tensor):
-        _check_inputs(label_tensor=label_tensor)
+        label_tensor = _inputs(label_tensor=label_tensor)
         B, _, H, W = (int(v) for v in label_tensor.shape)
         plan = E.Plan(label_tensor.device)
         return self._finish(plan, E.emit_cond_image_embedding(plan, _params_of(self, "m."), "m", label_tensor, B, H, W))
@@ -61,8 +61,12 @@ class ResBlock(nn.Module, _EagerMixin):
         self.out_ch = out_ch
 
     def forward(self, x, temb, cemb=None):
-        _check_inputs(x=x, temb=temb)
-        _refuse_dropout(self)
+        x, temb = _inputs(x=x, temb=temb)
+        if cemb is not None:
+            cemb = _inputs(cemb=cemb)
+        if _dropout_active(self):                  # train-mode nn.Dropout (Model.py:286): the eager path carries its kernels
+            from ..autograd import res_block
+            return res_block(self, x, None, temb, cemb, True)
         B, _, H, W = (int(v) for v in x.shape)
         plan = E.Plan(x.device)
         out = E.emit_resblock(plan, _params_of(self, "m."), "m", x, None, temb, cemb, self.out_ch, B, H, W, self.activate_attn)
@@ -158,12 +162,14 @@ class DynamicUNet(nn.Module):
         return up
 
     def forward(self, x, t, labels=None, context_zero=True):
-        _check_inputs(x=x, t=t)
+        x, t = _inputs(x=x, t=t)
         self.dynamic_forward(x)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError("hdiff: DynamicUNet runs inference only on the HIP path (call it under torch.no_grad()); "
                                       "this tree's trainer depends on pretrained perceptual networks and is out of scope")
-        _refuse_dropout(self)
+        if _dropout_active(self):
+            raise NotImplementedError("hdiff: DynamicUNet runs inference only on the HIP path: call .eval() (train-mode dropout "
+                                      "belongs to this tree's trainer, which is out of scope)")
         B, Cx, H, W = (int(v) for v in x.shape)
         if Cx != 6:
             raise RuntimeError(f"expected input[{B}, {Cx}, {H}, {W}] to have 6 channels")
@@ -173,7 +179,7 @@ class DynamicUNet(nn.Module):
         if not context_zero:
             if labels is None:
                 raise AttributeError("'NoneType' object has no attribute 'shape'")      # what the reference's conv would hit
-            _check_inputs(labels=labels)
+            labels = _inputs(labels=labels)
         up = self.plan_for(B, H, W, x.device, context_zero)
         up.cond.copy_(x[:, :3])
         up.y.copy_(x[:, 3:])

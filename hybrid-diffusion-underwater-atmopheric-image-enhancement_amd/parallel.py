@@ -53,8 +53,11 @@ def broadcast_parameters_(params: Iterable[torch.Tensor], src: int = 0) -> None:
     """Make every rank start from rank `src`'s weights (what DDP does at construction, rotinas.py:619)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
-    for p in params:
-        dist.broadcast(p.data, src=src)
+    with torch.no_grad():
+        for p in params:
+            buf = p.detach().clone()
+            dist.broadcast(buf, src=src)
+            p.copy_(buf)      # an in-place write autograd sees: bumps p._version, so cached weight packs are refreshed
 
 
 def allreduce_mean_grads_(params: Sequence[torch.nn.Parameter]) -> int:

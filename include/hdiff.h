@@ -168,9 +168,12 @@ int hdiff_mha_flash_fwd(const float* qkv, float* o, float* lse2 /*[B][heads][L] 
                         hdiff_stream_t stream);
 /* Backward of the core (autograd of nn.MultiheadAttention, TrainCondition.py:60): dqkv [B][3C][L] from dO [B][C][L].
  * lse2 is the forward's log2-domain log-sum-exp; delta is a [B][heads][L] workspace (rowsum(dO o O), written here).
- * P is recomputed, never stored; no atomics (bitwise reproducible). */
+ * P is recomputed, never stored; five MFMA products per tile in ONE kernel: a workgroup owns a key range (dK, dV in
+ * registers) and adds its dQ tiles to the partial slab of that range in ws, summed in range order afterwards -- no atomics,
+ * bitwise reproducible.  hdiff_mha_flash_bwd_workspace gives the size of ws in floats (0: ws may be NULL). */
+int hdiff_mha_flash_bwd_workspace(int B, int C, int heads, int L, int64_t* n_floats);
 int hdiff_mha_flash_bwd(const float* qkv, const float* o, const float* d_o, const float* lse2, float* delta, float* dqkv,
-                        int B, int C, int heads, int L, hdiff_stream_t stream);
+                        float* ws, int B, int C, int heads, int L, hdiff_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Small dense layers (K6, K10).  y[b][j] (+)= bias[j] + sum_k W[j][k] * f(x_row(b)[k]),  f = identity or Swish.
@@ -191,9 +194,10 @@ int hdiff_linear_rows_bwd(const float* x, const int64_t* idx, int n_rows, const 
 /* ------------------------------------------------------------------------------------------------------------------
  * Diffusion process (K11-K13), DiffusionFreeGuidence/DiffusionCondition.py.
  * ------------------------------------------------------------------------------------------------------------------ */
-/* q_sample (:43-44): x_t = sa[t[b]]*x0 + sb[t[b]]*noise ; sa/sb are the fp32 casts of the float64 schedule buffers. */
+/* q_sample (:43-44): x_t = sa[t[b]]*x0 + sb[t[b]]*noise ; sa/sb are the fp32 casts of the float64 schedule buffers, T their
+ * length: t[b] is clamped to [0, T) in the kernel (a bad index never faults the GPU; the host raises like extract's gather). */
 int hdiff_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ab, const float* sqrt_1mab,
-                   float* xt, int B, int per_sample, hdiff_stream_t stream);
+                   float* xt, int B, int per_sample, int T, hdiff_stream_t stream);
 /* unreduced squared error (:45): loss = (eps_hat - noise)^2 */
 int hdiff_sq_err(const float* a, const float* b, float* out, int64_t n, hdiff_stream_t stream);
 /* its backward: da = 2*(a-b)*dloss */

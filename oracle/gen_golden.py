@@ -13,6 +13,11 @@ Fixtures:
   G2 modules.npz          Swish, TimeEmbedding, ConditionalEmbedding, DownSample, UpSample, ResBlock x3 (+weights)
   G3 unet_small.npz       small UNet (ch=32, ch_mult=[1,2], nrb=1): state_dict, inputs, eps @16^2 and @32^2, per-layer taps
   G4 unet_default64.npz   default UNet (ch=128,[1,2,2,2],nrb=2) @64^2 B=1: seed recipe, weight checksums, input, eps
+  G4b unet_default128.npz default UNet @128^2 B=1 (BASELINE config C2's shape; the reference materialises 8 x 16384^2 scores
+                          = 8.6 GB per attention block): input, eps for label 1 and label 0   [python -m oracle.gen_golden g4b]
+  G5b sampler_default128.npz  the REAL reference sampler on the default UNet at 128x128 (config C2's shape), T = 3, w = 1.8,
+                          two independent B = 1 runs (the reference's batch entries do not interact), every draw recorded
+                          [python -m oracle.gen_golden g5b; ~8 min, ~25 GB]
   G5 sampler_small.npz    T=8 sampler on the small UNet, w in {0, 1.8}: x_T, per-step noise, pre-clip trajectory, output
   G6 trainer_small.npz    Trainer loss with recorded (t, noise); grads of named params; one clipped AdamW step
   G7 state_dict_default.json   the 366 (name, shape) pairs of the default UNet
@@ -222,6 +227,22 @@ def gen_unet_default64(RM):
                    "entries": [[k, list(v.shape)] for k, v in m.state_dict().items()]}, fh, indent=0)
 
 
+def gen_unet_default128(RM):
+    """G4b: the REAL reference at BASELINE config C2's shape (128x128, L = 16 384 at the first level), B = 1.
+    Same seed recipe as G4 (weights are pinned by G4's checksums); peak host memory ~25 GB."""
+    torch.manual_seed(DEFAULT_SEED)
+    m = RM.UNet(**DEFAULT).eval()
+    g = torch.Generator().manual_seed(4242)
+    x = torch.randn(1, 3, 128, 128, generator=g)
+    t = torch.tensor([133])
+    out = {"temb_row_133": _np(m.time_embedding.timembedding[0].weight[133]), "seed": np.array([DEFAULT_SEED]),
+           "cfg_json": np.frombuffer(json.dumps(DEFAULT).encode(), dtype=np.uint8), "x": _np(x), "t": _np(t)}
+    with torch.no_grad():
+        for lab in (2, 0):
+            out[f"eps_label{lab}"] = _np(m(x, t, torch.tensor([lab])))
+    np.savez_compressed(os.path.join(OUT, "unet_default128.npz"), **out)
+
+
 def gen_sampler_small(RM, RD):
     m = _small_model(RM)
     # random default-init weights saturate the trajectory; shrink the tail conv so x_t stays O(1) (SURVEY 8c note)
@@ -246,6 +267,36 @@ def gen_sampler_small(RM, RD):
         out[f"{tag}/traj_preclip"] = np.stack([_np(v) for v in rec.isnan_in])   # order: time_step T-1 ... 0
         out[f"{tag}/x_0"] = _np(y)
     np.savez_compressed(os.path.join(OUT, "sampler_small.npz"), **out)
+
+
+def gen_sampler_default128(RM, RD):
+    """G5b: three ancestral steps of the reference's own sampler at 128x128 on the seed-recipe default UNet, one sample at a
+    time (B = 2 at once would hold 2 x 17 GB of scores per attention block); the GPU test runs both as one batch."""
+    torch.manual_seed(DEFAULT_SEED)
+    m = RM.UNet(**dict(DEFAULT, T=3)).eval()
+    T = 3
+    out = {"beta": np.array([1e-4, 0.028]), "w": np.array([1.8]), "T": np.array([T]), "seed": np.array([DEFAULT_SEED]),
+           "temb_table_T3": _np(m.time_embedding.timembedding[0].weight)}
+    g = torch.Generator().manual_seed(31337)
+    samp = RD.GaussianDiffusionSampler(m, 1e-4, 0.028, T, w=1.8)
+    xs, labs, noises, trajs, outs = [], [], [], [], []
+    for i, lab in enumerate((1, 2)):
+        x_T = torch.randn(1, 3, 128, 128, generator=g)
+        labels = torch.tensor([lab])
+        torch.manual_seed(600 + i)
+        with _Recorder() as rec, torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            y = samp(x_T, labels)
+        noise = np.zeros((T, 1, 3, 128, 128), dtype=np.float32)
+        for k, r in enumerate(rec.randn):
+            noise[T - 1 - k] = _np(r)
+        xs.append(_np(x_T)); labs.append(lab); noises.append(noise)
+        trajs.append(np.stack([_np(v) for v in rec.isnan_in])); outs.append(_np(y))
+    out["x_T"] = np.concatenate(xs, 0)
+    out["labels"] = np.array(labs, dtype=np.int64)
+    out["noise_by_step"] = np.concatenate(noises, 1)            # [T][2][3][128][128], indexed by time_step
+    out["traj_preclip"] = np.concatenate(trajs, 1)              # order: time_step T-1 ... 0
+    out["x_0"] = np.concatenate(outs, 0)
+    np.savez_compressed(os.path.join(OUT, "sampler_default128.npz"), **out)
 
 
 def gen_trainer_small(RM, RD):
@@ -303,6 +354,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     RD, RM = RL.load_diffusion(), RL.load_model()
+    if len(sys.argv) > 1 and sys.argv[1] == "g4b":      # the large fixture alone (minutes, ~25 GB of host memory)
+        gen_unet_default128(RM)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g5b":
+        gen_sampler_default128(RM, RD)
+        return
     gen_schedules(RD)
     gen_modules(RM)
     gen_unet_small(RM)

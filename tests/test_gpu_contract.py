@@ -1,0 +1,205 @@
+"""GPU tests of the drop-in contract's edges: what the reference does with bad indices, strided inputs, a changed guidance
+weight, train-mode dropout without autograd, weights rewritten behind autograd's back -- and that a bad index can never fault
+the GPU (the gather kernels clamp; the host raises what the reference raises).
+
+Reference behaviour cited per test (paths relative to /root/reference/DiffusionFreeGuidence/).
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import hdiff_amd  # noqa: E402
+from hdiff_amd import _capi  # noqa: E402
+from hdiff_amd.DiffusionFreeGuidence import DiffusionCondition as DC  # noqa: E402
+from hdiff_amd.DiffusionFreeGuidence import ModelCondition as MC  # noqa: E402
+
+DEV = "cuda:0"
+SMALL = dict(T=8, num_labels=3, ch=32, ch_mult=[1, 2], num_res_blocks=1, dropout=0.0)
+
+
+def small(seed=1, **over):
+    torch.manual_seed(seed)
+    return MC.UNet(**dict(SMALL, **over))
+
+
+def test_gather_kernels_clamp_out_of_range_rows():
+    """hdiff_linear_rows / _bwd / hdiff_q_sample called straight through the C ABI with indices outside the table: the
+    result is that of the clamped index and the call returns cleanly (pins the fix of round 1's abort, where a recycled
+    index buffer sent the gather to garbage rows).  Run once; nothing here tries to provoke a fault."""
+    g = torch.Generator().manual_seed(1)
+    n_rows, K, N = 20, 128, 64
+    table = torch.randn(n_rows, K, generator=g).to(DEV)
+    W, b = (torch.randn(N, K, generator=g) / 11).to(DEV), torch.randn(N, generator=g).to(DEV)
+    bad = torch.tensor([-5, 3, 25, 2 ** 40, -2 ** 40, 19], dtype=torch.int64, device=DEV)
+    good = bad.clamp(0, n_rows - 1)
+    lib, s = _capi.lib(), torch.cuda.current_stream().cuda_stream
+    y_bad, y_good = torch.empty(6, N, device=DEV), torch.empty(6, N, device=DEV)
+    for idx, y in ((bad, y_bad), (good, y_good)):
+        _capi.check(lib.hdiff_linear_rows(table.data_ptr(), idx.data_ptr(), n_rows, W.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                          6, K, N, 0, 0, s), "linear_rows")
+    torch.cuda.synchronize()
+    assert torch.equal(y_bad, y_good)
+    assert (y_good - (table[good] @ W.t() + b)).abs().max().item() < 1e-4
+    dy = torch.randn(6, N, generator=g).to(DEV)
+    outs = []
+    for idx in (bad, good):
+        dx, dW, db = torch.zeros(n_rows, K, device=DEV), torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+        _capi.check(lib.hdiff_linear_rows_bwd(table.data_ptr(), idx.data_ptr(), n_rows, W.data_ptr(), dy.data_ptr(),
+                                              dx.data_ptr(), dW.data_ptr(), db.data_ptr(), 6, K, N, 0, 0, 0, s), "bwd")
+        outs.append((dx, dW, db))
+    torch.cuda.synchronize()
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    assert outs[0][0][0].abs().max().item() == 0.0            # pad_row = 0 gets no gradient although three indices clamp to it
+    # q_sample: t outside [0, T)
+    T, per = 10, 3 * 8 * 8
+    sa, sb = torch.linspace(1, 0.1, T).to(DEV), torch.linspace(0, 0.9, T).to(DEV)
+    x0, nz = torch.randn(3, per, generator=g).to(DEV), torch.randn(3, per, generator=g).to(DEV)
+    t_bad = torch.tensor([-1, T + 5, 4], dtype=torch.int64, device=DEV)
+    out = torch.empty(3, per, device=DEV)
+    _capi.check(lib.hdiff_q_sample(x0.data_ptr(), nz.data_ptr(), t_bad.data_ptr(), sa.data_ptr(), sb.data_ptr(),
+                                   out.data_ptr(), 3, per, T, s), "q_sample")
+    tc = t_bad.clamp(0, T - 1)
+    assert torch.equal(out, sa[tc][:, None] * x0 + sb[tc][:, None] * nz)
+
+
+def test_bad_indices_raise_like_the_reference():
+    """nn.Embedding raises IndexError for t >= T or labels > num_labels (ModelCondition.py:38,56 -> 257-258); extract's
+    torch.gather raises RuntimeError for a time step outside the schedule (DiffusionCondition.py:13)."""
+    m = small().to(DEV).eval()
+    x = torch.randn(2, 3, 16, 16, device=DEV)
+    ok_t, ok_l = torch.tensor([0, 7], device=DEV), torch.tensor([3, 0], device=DEV)
+    with torch.no_grad():
+        m(x, ok_t, ok_l)
+        for t, lab in ((torch.tensor([0, 8], device=DEV), ok_l), (torch.tensor([-1, 2], device=DEV), ok_l),
+                       (ok_t, torch.tensor([4, 0], device=DEV)), (ok_t, torch.tensor([1, -1], device=DEV))):
+            with pytest.raises(IndexError):
+                m(x, t, lab)
+        assert torch.equal(m(x, ok_t.to(torch.int32), ok_l.to(torch.int32)), m(x, ok_t, ok_l))     # int32 indices as nn.Embedding
+    mt = small().to(DEV).train()
+    with pytest.raises(IndexError):                            # the training (autograd) path validates too
+        mt(x, torch.tensor([0, 8], device=DEV), ok_l)
+    tr = DC.GaussianDiffusionTrainer(mt, 1e-4, 0.02, 8).to(DEV)
+    with pytest.raises(RuntimeError, match="out of bounds"):
+        tr(x, ok_l, t=torch.tensor([0, 8], device=DEV))      # raised before any kernel sees the index
+    samp = DC.GaussianDiffusionSampler(m, 1e-4, 0.02, 8, w=1.0).to(DEV)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="out of bounds"):
+        samp.predict_xt_prev_mean_from_eps(x, torch.tensor([8, 0], device=DEV), x)
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        samp.predict_xt_prev_mean_from_eps(x, torch.tensor([1.0, 0.0], device=DEV), x)               # float index: gather refuses
+    with torch.no_grad(), pytest.raises(IndexError):
+        samp(x, torch.tensor([9, 0], device=DEV))
+
+
+def test_sampler_reads_w_and_weights_at_call_time():
+    """The reference evaluates self.w on every step (DiffusionCondition.py:78) and reads the live weights; a captured step
+    must follow a changed sampler.w, and a write through p.data (which autograd's version counter does not see)."""
+    m = small().to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    x_T = torch.randn(2, 3, 16, 16, generator=g).to(DEV)
+    lab = torch.tensor([1, 2], device=DEV)
+    z = torch.randn(8, 2, 3, 16, 16, generator=g).to(DEV)
+    with torch.no_grad():
+        s0 = DC.GaussianDiffusionSampler(m, 1e-4, 0.028, 8, w=0.0).to(DEV)
+        a0 = s0(x_T, lab, noise_by_step=z)
+        s0.w = 1.8
+        a18 = s0(x_T, lab, noise_by_step=z)
+        fresh = DC.GaussianDiffusionSampler(m, 1e-4, 0.028, 8, w=1.8).to(DEV)(x_T, lab, noise_by_step=z)
+        assert not torch.equal(a0, a18) and torch.equal(a18, fresh)
+        # weights rewritten through .data after a plan exists
+        m.tail[2].weight.data.mul_(0.5)
+        m.downblocks[0].attn.in_proj_weight.data.add_(0.01)
+        b = s0(x_T, lab, noise_by_step=z)
+        m2 = small().to(DEV).eval()
+        m2.load_state_dict(m.state_dict())
+        want = DC.GaussianDiffusionSampler(m2, 1e-4, 0.028, 8, w=1.8).to(DEV)(x_T, lab, noise_by_step=z)
+        assert not torch.equal(b, a18) and torch.equal(b, want)
+        # UNet.forward alone: explicit invalidation for .data writes, automatic for versioned writes
+        t = torch.tensor([3, 4], device=DEV)
+        y0 = m(x_T, t, lab)
+        m.head.bias.data.add_(0.25)
+        m.invalidate_packed()
+        y1 = m(x_T, t, lab)
+        assert not torch.equal(y0, y1)
+        m.head.weight.mul_(1.5)                                  # versioned in-place write: seen without any call
+        assert torch.equal(m(x_T, t, lab), m2_like(m, x_T, t, lab))
+
+
+def m2_like(m, x, t, lab):
+    m2 = small().to(DEV).eval()
+    m2.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        return m2(x, t, lab)
+
+
+def test_strided_inputs_are_accepted():
+    m = small().to(DEV).eval()
+    g = torch.Generator().manual_seed(4)
+    big = torch.randn(2, 3, 32, 32, generator=g).to(DEV)
+    x = big[:, :, ::2, ::2]                                      # a strided view, as the reference's ATen ops accept
+    assert not x.is_contiguous()
+    t, lab = torch.tensor([1, 5], device=DEV), torch.tensor([2, 0], device=DEV)
+    tt = torch.stack([t, t], dim=1)[:, 0]                        # strided index vector
+    with torch.no_grad():
+        assert torch.equal(m(x, tt, lab), m(x.contiguous(), t, lab))
+        samp = DC.GaussianDiffusionSampler(m, 1e-4, 0.028, 8, w=1.0).to(DEV)
+        z = torch.randn(8, 2, 3, 16, 16, generator=g).to(DEV)
+        assert torch.equal(samp(x, lab, noise_by_step=z), samp(x.contiguous(), lab, noise_by_step=z))
+        tr = DC.GaussianDiffusionTrainer(m, 1e-4, 0.028, 8).to(DEV)
+        nz = torch.randn(2, 3, 16, 16, generator=g).to(DEV)
+        assert torch.equal(tr(x, lab, t=t, noise=nz), tr(x.contiguous(), lab, t=t, noise=nz))
+
+
+def test_train_mode_dropout_without_autograd():
+    """nn.Dropout acts in train mode whether or not autograd records (ModelCondition.py:185): under torch.no_grad() a
+    train-mode model must run (with dropout), not raise."""
+    m = small(dropout=0.3).to(DEV)
+    x = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(5)).to(DEV)
+    t, lab = torch.tensor([1, 5], device=DEV), torch.tensor([2, 0], device=DEV)
+    with torch.no_grad():
+        m.eval()
+        y_eval = m(x, t, lab)
+        m.train()
+        torch.manual_seed(10); y1 = m(x, t, lab)
+        torch.manual_seed(10); y2 = m(x, t, lab)
+        torch.manual_seed(11); y3 = m(x, t, lab)
+        assert torch.isfinite(y1).all() and torch.equal(y1, y2)
+        assert not torch.equal(y1, y3) and not torch.equal(y1, y_eval)
+        # a ResBlock on its own, train mode
+        rb = MC.ResBlock(32, 32, 64, 0.5, attn=False).to(DEV).train()
+        h, temb, cemb = torch.randn(2, 32, 8, 8, device=DEV), torch.randn(2, 64, device=DEV), torch.randn(2, 64, device=DEV)
+        torch.manual_seed(1); r1 = rb(h, temb, cemb)
+        torch.manual_seed(1); r2 = rb(h, temb, cemb)
+        assert torch.equal(r1, r2) and not torch.equal(r1, rb.eval()(h, temb, cemb))
+
+
+def test_plane_count_beyond_65535():
+    """B * C >= 65 536 planes (a batch of 128 with the 512-channel concat blocks): the apply kernels index planes on
+    gridDim.x, not on the 65 535-limited y."""
+    B, Cc, HW, G = 130, 512, 16, 32
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(B, Cc, HW, device=DEV, generator=g)
+    scale, shift = torch.rand(B, Cc, device=DEV, generator=g) + 0.5, torch.randn(B, Cc, device=DEV, generator=g)
+    y = torch.empty_like(x)
+    lib, s = _capi.lib(), torch.cuda.current_stream().cuda_stream
+    _capi.check(lib.hdiff_gn_swish_apply(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, Cc, HW, s), "apply")
+    a = x * scale[:, :, None] + shift[:, :, None]
+    assert (y - a * torch.sigmoid(a)).abs().max().item() < 1e-5
+    # backward through the autograd wrapper's kernel (hdiff_gn_swish_bwd) against torch autograd in float64
+    gamma, beta = torch.rand(Cc, device=DEV, generator=g) + 0.5, torch.randn(Cc, device=DEV, generator=g)
+    dA = torch.randn(B, Cc, HW, device=DEV, generator=g)
+    x64 = x.double().requires_grad_(True)
+    a64 = torch.nn.functional.group_norm(x64, G, gamma.double(), beta.double(), 1e-5)
+    (a64 * torch.sigmoid(a64)).backward(dA.double())
+    xr = x.view(B, G, -1)
+    mean = xr.mean(-1)
+    rstd = 1.0 / torch.sqrt(xr.var(-1, unbiased=False) + 1e-5)
+    ws = torch.empty(2 * B * Cc + 2 * B * G, device=DEV)
+    dx, dgw, dgb = torch.empty_like(x), torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+    _capi.check(lib.hdiff_gn_swish_bwd(x.data_ptr(), None, Cc, 0, B, HW, G, dA.data_ptr(), mean.contiguous().data_ptr(),
+                                       rstd.contiguous().data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(),
+                                       dx.data_ptr(), None, dgw.data_ptr(), dgb.data_ptr(), s), "gn_swish_bwd")
+    assert (dx.double() - x64.grad).abs().max().item() < 1e-4 * x64.grad.abs().max().item()
