@@ -321,6 +321,12 @@ extern "C" int hdiff_conv2d_wgrad(const hdiff_conv_wgrad_desc* d, float* dwp, in
   k.PW = (TW - 1) * d->in_stride + (dx_max - dx_min + 1);
   k.PWp = k.PW | 1;
   k.PLANE = k.PH * k.PWp;
+  // Bank-conflict-free B-operand reads: lane j of an N tile reads column (channel j / ntaps, tap j % ntaps) at
+  // channel * PLANE + tap_off.  With PWp = 3 (mod 32) the nine taps of a 3x3 stencil fall on nine consecutive banks, and with
+  // PLANE = ntaps (mod 32) consecutive channels continue the run: 32 consecutive columns hit 32 different banks
+  // (the unpadded 210-float plane put channels 0 and 2 on overlapping banks: 1.5 conflict cycles per read, round 1 PMC).
+  if (d->ntaps == 9 && (k.PWp & 31) == 3 && dx_max - dx_min == 2 && dy_max - dy_min == 2)
+    k.PLANE += ((9 - k.PLANE) % 32 + 32) % 32;
   for (int t = 0; t < d->ntaps; ++t) k.tap_off[t] = (d->tap_dy[t] - dy_min) * k.PWp + (d->tap_dx[t] - dx_min);
   k.CKW = d->ntaps == 1 ? 32 : (d->ntaps > 9 ? 4 : 16);
   k.ncol = k.CKW * d->ntaps;

@@ -1,7 +1,8 @@
 """GPU parity at the shapes of BASELINE.json's configs that the oracle cannot finish in seconds:
 
   C2  128x128 sampling        the REAL reference's eps at 128x128, B = 1 (tests/golden/unet_default128.npz, made by
-                              ``python -m oracle.gen_golden g4b``); teacher-forced sampler steps at B = 2 vs the CPU oracle
+                              ``python -m oracle.gen_golden g4b``); three teacher-forced sampler steps at B = 2 against the
+                              REAL reference's sampler (sampler_default128.npz, ``... gen_golden g5b``)
   C3  256x256 training        the full-size backward kernels: attention backward at (L = 65 536, d_head 16) and
                               (L = 16 384, d_head 32) against a float64 evaluation of one whole head; conv wgrad / dgrad /
                               GroupNorm-Swish backward at 256x256 (128 -> 128 and the 384 -> 128 concat) against the float64
@@ -69,30 +70,30 @@ def test_c2_unet_128_against_the_real_reference():
     assert abs(flops / 529.6e9 - 1.0) < 0.01, flops
 
 
-def test_c2_sampler_steps_128_vs_oracle():
-    """Three teacher-forced denoising steps at 128x128, B = 2, w = 1.8 (config C2's per-step work) against the CPU oracle."""
-    m = default_model(0).eval()
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    cfg = O.UNetConfig(T=3, num_labels=10, ch=128, ch_mult=(1, 2, 2, 2), num_res_blocks=2)
-    m3 = MC.UNet(**dict(DEFAULT, T=3))
-    sd3 = dict(sd)
-    sd3["time_embedding.timembedding.0.weight"] = m3.state_dict()["time_embedding.timembedding.0.weight"].clone()
-    m3.load_state_dict(sd3)
-    g = torch.Generator().manual_seed(21)
-    x_T = torch.randn(2, 3, 128, 128, generator=g)
-    labels = torch.tensor([1, 2])
-    z = torch.randn(3, 2, 3, 128, 128, generator=g)
+def test_c2_sampler_steps_128_against_the_real_reference():
+    """Three teacher-forced ancestral steps at 128x128, w = 1.8, B = 2 as ONE batch (config C2's per-step work) against the
+    reference's own sampler (tests/golden/sampler_default128.npz: two B = 1 runs of the real reference, every random draw
+    recorded -- the reference's batch entries do not interact)."""
+    d = np.load(os.path.join(GOLDEN, "sampler_default128.npz"))
+    T = int(d["T"][0])
+    torch.manual_seed(int(d["seed"][0]))
+    m = MC.UNet(**dict(DEFAULT, T=T))
     with torch.no_grad():
-        want = O.sampler_forward(sd3, cfg, 1e-4, 0.028, 3, 1.8, x_T, labels, list(z))
-        samp = DC.GaussianDiffusionSampler(m3.to(DEV).eval(), 1e-4, 0.028, 3, w=1.8).to(DEV)
+        m.time_embedding.timembedding[0].weight.copy_(T_(d["temb_table_T3"]))          # sin/cos last-bit differences between CPUs
+    m = m.to(DEV).eval()
+    b1, bT = [float(v) for v in d["beta"]]
+    samp = DC.GaussianDiffusionSampler(m, b1, bT, T, w=float(d["w"][0])).to(DEV)
+    x_T, labels, z = T_(d["x_T"]).to(DEV), T_(d["labels"]).to(DEV), T_(d["noise_by_step"]).to(DEV)
+    with torch.no_grad():
         traj = []
-        got = samp(x_T.to(DEV), labels.to(DEV), noise_by_step=z.to(DEV), trajectory=traj)
-        again = samp(x_T.to(DEV), labels.to(DEV), noise_by_step=z.to(DEV))            # hipGraph replay
-    e = maxerr(got, want)
-    print(f"3 sampler steps at 128x128 B=2: max err {e:.3e}, pre-clip |x| max {traj[-1].abs().max().item():.2f}")
-    assert e < 1e-3
+        got = samp(x_T, labels, noise_by_step=z, trajectory=traj)                        # eager launches, per-step states
+        again = samp(x_T, labels, noise_by_step=z)                                        # hipGraph replay
+    errs = [maxerr(x, T_(d["traj_preclip"][i])) for i, x in enumerate(traj)]
+    print("128x128 B=2 per-step max err", ["%.2e" % e for e in errs], "pre-clip |x| max %.2f" % traj[-1].abs().max().item())
+    assert max(errs) < 1e-3
     assert torch.equal(got, again)
-    assert O.psnr(got.cpu() * 0.5 + 0.5, want * 0.5 + 0.5) > 60.0
+    assert maxerr(got, T_(d["x_0"])) < 1e-3
+    assert O.psnr(got.cpu() * 0.5 + 0.5, T_(d["x_0"]) * 0.5 + 0.5) > 60.0
 
 
 # ----------------------------------------------------------------------------------------------------------------------
