@@ -8,10 +8,16 @@ cond + uncond UNet forward (one 2B-batched launch sequence) + fused CFG/posterio
 are resident in HBM before the timed region.  Sampling shards by image: every rank runs its own batch with its own seed
 and there is no data-path collective (weak scaling); value = N * K / max-over-ranks wall time.
 
+The timed region replays the hipGraph-captured step (the north-star formulation; ``--eager`` times plain launches instead).
+Per-kernel durations come from a second pass of the same K steps issued as plain launches with HIP events recorded on the
+launch stream around the launches of interest (events cannot bracket nodes inside a graph replay; the kernels, their
+arguments and their order are identical -- the two passes agree to < 0.1 % at this size, both wall times are reported).
+
 Rank 0 prints ONE JSON line with the contract keys plus
-  roofline      dominant kernel (flash attention at L = 65536, d_head = 16) against the fp32-MFMA peak, timed live with
-                HIP events recorded on the launch stream around every such launch inside the timed region
-  cpu_baseline  the CPU oracle (oracle/cpu_path.py, kind "port") timed on the host cores on a bounded sample
+  roofline      dominant kernel (flash attention at L = 65536, d_head = 16) against the fp32-MFMA peak; ``secondary`` holds
+                the full-resolution 3x3 convolution (MFMA) and the GroupNorm statistics pass (HBM) the same way
+  cpu_baseline  the CPU oracle (oracle/cpu_path.py, kind "port"): one whole UNet forward at 128x128 timed on the host
+                cores (a bounded sample, ~25 s), scaled to the benchmark's step by the algorithmic FLOP ratio
 """
 import argparse
 import ctypes as C
@@ -31,6 +37,7 @@ BETA = (1e-4, 0.02)
 GUIDANCE_W = 1.8
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak (= fp32 vector peak)
 PEAK_BF16_MFMA_TFLOPS = 2516.6    # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak (spec); ~6.3 TB/s is what a float4 copy achieves
 # algorithmic FLOPs per sample per UNet forward (torch flop counter on the reference UNet)
 FWD_GFLOP = {64: 74.0, 128: 529.6, 256: 5857.4, 512: 83254.1}
 
@@ -46,14 +53,16 @@ def parse():
     ap.add_argument("--contract", choices=["f32", "bf16x3"], default="f32",
                     help="attention contractions: fp32-input MFMA (default) or the fp32-class three-piece bf16 split")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed in `value`) run in the other contraction mode")
-    ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph instead of eager launches "
-                    "(no per-kernel events inside the timed region)")
+    ap.add_argument("--eager", action="store_true", help="time plain launches instead of the hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second, event-instrumented pass (no roofline)")
     return ap.parse_args()
 
 
 def cpu_baseline(size, batch):
-    """Oracle on the host cores: full denoising steps (2 UNet forwards + update each) at 64x64, B=1 (about 10-30 s of CPU
-    work), extrapolated to the benchmark's workload by the algorithmic FLOP ratio and the batch."""
+    """Oracle on the host cores: ONE whole UNet forward at 128x128, B = 1 (the largest size that finishes in tens of
+    seconds; attention is 60 % of its FLOPs against 85 % at 256x256), scaled to one denoising step of the benchmark
+    (2 * batch forwards at `size`) by the algorithmic FLOP ratio."""
     from oracle import cpu_path as O
     threads = min(os.cpu_count() or 1, 16)          # the one-GPU box's CPU share
     torch.set_num_threads(threads)
@@ -63,22 +72,21 @@ def cpu_baseline(size, batch):
     sd = {k: v.detach() for k, v in m.state_dict().items()}
     cfg = O.UNetConfig(T=MODEL["T"], num_labels=MODEL["num_labels"], ch=MODEL["ch"], ch_mult=tuple(MODEL["ch_mult"]),
                        num_res_blocks=MODEL["num_res_blocks"])
-    S, nsteps = 64, 4
+    S = 128
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, 3, S, S, generator=g)
-    sched = O.sampler_schedule(BETA[0], BETA[1], MODEL["T"])
     with torch.no_grad():
         O.unet_forward(sd, cfg, torch.randn(1, 3, 32, 32, generator=g), torch.tensor([5]), torch.tensor([1]))  # warm
         t0 = time.perf_counter()
-        for i in range(nsteps):
-            x = O.denoise_step(sd, cfg, sched, GUIDANCE_W, x, 500 - i, torch.tensor([1]),
-                               torch.randn(1, 3, S, S, generator=g))
-        dt = (time.perf_counter() - t0) / nsteps
-    scale = FWD_GFLOP[size] / FWD_GFLOP[S] * batch if size in FWD_GFLOP else (size / S) ** 4 * batch
+        O.unet_forward(sd, cfg, x, torch.tensor([500]), torch.tensor([1]))
+        dt = time.perf_counter() - t0
+    fwd = FWD_GFLOP[size] if size in FWD_GFLOP else FWD_GFLOP[S] * (size / S) ** 4
+    scale = 2 * batch * fwd / FWD_GFLOP[S]
     return {"value": 1.0 / (dt * scale), "unit": "denoising-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{nsteps} denoising steps at {S}x{S}, B=1 on the CPU oracle took {dt:.2f} s each; scaled by the algorithmic "
-                      f"FLOP ratio x batch ({scale:.1f}x) to {size}x{size}, B={batch} "
-                      "(the reference's own materialised-attention formulation cannot run at 256x256: 137 GB/sample)",
+            "sample": f"one UNet forward at {S}x{S}, B=1 on the CPU oracle (blockwise attention) took {dt:.1f} s = "
+                      f"{FWD_GFLOP[S] / dt:.0f} GFLOP/s; one step of the benchmark is 2x{batch} forwards at {size}x{size} = "
+                      f"{scale:.0f}x its FLOPs (the reference's own materialised-attention formulation cannot run at "
+                      "256x256: 137 GB/sample)",
             "measured_s": dt, "torch_threads": threads}
 
 
@@ -121,20 +129,33 @@ def main():
         sp.step.fill_(MODEL["T"] - 1)
         sp.nan_flag.zero_()
         stream = torch.cuda.current_stream(dev).cuda_stream
-        if a.graph:
+        use_graph = not a.eager
+        if use_graph:
             plan.capture()
 
-        # locate the dominant kernel: attention launches over the full-resolution token set
+        # launches of interest: attention over the full-resolution token set (dominant), the full-resolution 128 -> 128 3x3
+        # convolutions, the full-resolution GroupNorm statistics passes
         L_full = S * S
-        att_idx = [i for i, (name, _, args) in enumerate(plan.ops) if name == "hdiff_mha_flash_fwd" and args[6] == L_full]
-        events = []
+        Cc = MODEL["ch"] * MODEL["ch_mult"][0]
+        groups = {"attn": [], "conv3x3": [], "gn_stats": []}
+        for i, (name, _, args) in enumerate(plan.ops):
+            if name == "hdiff_mha_flash_fwd" and args[6] == L_full:
+                groups["attn"].append(i)
+            elif name == "hdiff_conv2d_fwd":
+                d = args[0]._obj
+                if d.ntaps == 9 and d.C0 == Cc and d.C1 == 0 and d.Cout == Cc and d.H == S and d.in_stride == 1:
+                    groups["conv3x3"].append(i)
+            elif name == "hdiff_gn_stats" and args[5] == L_full and args[2] + args[3] == Cc:
+                groups["gn_stats"].append(i)
+        hooked = {i: g for g, idx in groups.items() for i in idx}
+        events = {g: [] for g in groups}
 
-        def one_step(timed):
-            if a.graph:
+        def one_step(instrumented=False):
+            if use_graph and not instrumented:
                 plan.replay()
                 return
             for i, (name, fn, args) in enumerate(plan.ops):
-                hook = timed and i in att_idx
+                hook = instrumented and i in hooked
                 if hook:
                     e0, e1 = C.c_void_p(), C.c_void_p()
                     lib.hdiff_event_create(C.byref(e0)); lib.hdiff_event_create(C.byref(e1))
@@ -144,16 +165,16 @@ def main():
                     _capi.check(rc, name)
                 if hook:
                     lib.hdiff_event_record(e1, stream)
-                    events.append((e0, e1))
+                    events[hooked[i]].append((e0, e1))
 
         for _ in range(Wm):
-            one_step(False)
+            one_step()
         if dist:
             td.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(K):
-            one_step(True)
+            one_step()
         torch.cuda.synchronize(dev)
         if dist:
             td.barrier()
@@ -161,16 +182,28 @@ def main():
         assert int(sp.nan_flag.item()) == 0, "nan in tensor."
         assert int(sp.step.item()) == MODEL["T"] - 1 - (K + Wm)
 
-        # the other contraction mode, reported beside the headline (never part of `value`)
-        alt = None
-        if world == 1 and not a.no_alt and not a.graph:
-            other = "bf16x3" if a.contract == "f32" else "f32"
-            hdiff_amd.set_contraction_mode(other)
-            one_step(False)
+        # second pass: the same K steps as plain launches with HIP events around the launches of interest
+        kernel_pass_s = None
+        if not a.no_kernel_pass:
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for _ in range(K):
-                one_step(False)
+                one_step(instrumented=True)
+            torch.cuda.synchronize(dev)
+            kernel_pass_s = (time.perf_counter() - t1) / K
+            assert int(sp.nan_flag.item()) == 0, "nan in tensor."
+
+        # the other contraction mode, reported beside the headline (never part of `value`)
+        alt = None
+        if world == 1 and not a.no_alt:
+            other = "bf16x3" if a.contract == "f32" else "f32"
+            hdiff_amd.set_contraction_mode(other)
+            use_graph = False                         # a captured graph bakes the contraction mode: plain launches here
+            one_step()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(K):
+                one_step()
             torch.cuda.synchronize(dev)
             dt_alt = (time.perf_counter() - t1) / K
             hdiff_amd.set_contraction_mode(a.contract)
@@ -185,27 +218,30 @@ def main():
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    att_ms = []
-    for e0, e1 in events:
-        ms = C.c_float()
-        lib.hdiff_event_elapsed_ms(e0, e1, C.byref(ms))
-        att_ms.append(ms.value)
-        lib.hdiff_event_destroy(e0); lib.hdiff_event_destroy(e1)
+    durations = {}
+    for gname, evs in events.items():
+        vals = []
+        for e0, e1 in evs:
+            ms = C.c_float()
+            lib.hdiff_event_elapsed_ms(e0, e1, C.byref(ms))
+            vals.append(ms.value)
+            lib.hdiff_event_destroy(e0); lib.hdiff_event_destroy(e1)
+        durations[gname] = vals
 
     if rank == 0:
-        Cc = MODEL["ch"] * MODEL["ch_mult"][0]
+        traffic_tab = {}
+        prof = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.isfile(prof):
+            try:
+                traffic_tab = json.load(open(prof))
+            except Exception:
+                traffic_tab = {}
         flops_per_launch = 4.0 * L_full * L_full * Cc * (2 * B)          # QK^T + PV over 8 heads, 2B samples (CFG)
         roof = None
+        att_ms = durations.get("attn") or []
         if att_ms:
             avg = sum(att_ms) / len(att_ms)
             ach = flops_per_launch / (avg * 1e-3) / 1e12
-            traffic = None
-            prof = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-            if os.path.isfile(prof):
-                try:
-                    traffic = json.load(open(prof)).get(f"mha_flash_fwd_L{L_full}_B{2 * B}")
-                except Exception:
-                    traffic = None
             if a.contract == "f32":
                 kname, peak = "mha_flash_fwd_fast_kernel<16,4>", PEAK_F32_MFMA_TFLOPS
             else:   # six bf16 products per fp32 product: the scheme's fp32-equivalent ceiling is the bf16 dense peak / 6
@@ -214,9 +250,35 @@ def main():
                     "kernel": f"hdiff_mha_flash_fwd = {kname} + overflow-check pass, L={L_full} d_head=16 "
                               f"heads=8 batch={2 * B}",
                     "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic,
+                    "frac": round(ach / peak, 4), "traffic": traffic_tab.get(f"mha_flash_fwd_L{L_full}_B{2 * B}"),
                     "avg_launch_ms": round(avg, 3), "launches_timed": len(att_ms),
-                    "algorithmic_flop_per_launch": flops_per_launch}
+                    "algorithmic_flop_per_launch": flops_per_launch,
+                    "timed_in": "second pass of the same K steps as plain launches (HIP events on the launch stream)",
+                    "secondary": []}
+            conv_ms = durations.get("conv3x3") or []
+            if conv_ms and a.contract == "f32":
+                avg = sum(conv_ms) / len(conv_ms)
+                fl = 2.0 * 9 * Cc * Cc * L_full * (2 * B)
+                ach = fl / (avg * 1e-3) / 1e12
+                roof["secondary"].append({
+                    "bound": "mfma", "kernel": f"hdiff_conv2d_fwd = conv_igemm_kernel 3x3 {Cc}->{Cc} at {S}x{S}, batch {2 * B} "
+                                               "(GroupNorm-Swish prologue, bias/vector/residual epilogue)",
+                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_ms": round(avg, 3),
+                    "launches_timed": len(conv_ms), "algorithmic_flop_per_launch": fl,
+                    "traffic": traffic_tab.get(f"conv3x3_{Cc}_{S}_B{2 * B}")})
+            gn_ms = durations.get("gn_stats") or []
+            if gn_ms:
+                avg = sum(gn_ms) / len(gn_ms)
+                by = 4.0 * Cc * L_full * (2 * B)                       # the activation is read once; 2*C floats written
+                ach = by / (avg * 1e-3) / 1e9
+                roof["secondary"].append({
+                    "bound": "hbm", "kernel": f"hdiff_gn_stats = gn_stats_kernel, {Cc} channels at {S}x{S}, batch {2 * B} "
+                                              "(inside the step its input was just written by the producing conv: partly "
+                                              "L2 / Infinity-Cache resident; cold-HBM rate: profiles/, tools/gn_once.py)",
+                    "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                    "avg_launch_ms": round(avg, 4), "launches_timed": len(gn_ms), "algorithmic_bytes_per_launch": by,
+                    "traffic": traffic_tab.get(f"gn_stats_{Cc}_{S}_B{2 * B}")})
         step_tflop = 2 * B * FWD_GFLOP.get(S, 0.0) / 1e3
         out = {
             "metric": "denoising-steps/sec (256x256, T=1000)" if S == 256 else f"denoising-steps/sec ({S}x{S}, T=1000)",
@@ -227,7 +289,8 @@ def main():
             "config": {"workload": f"CFG-DDPM sampling, {S}x{S}, T=1000 linear schedule (1e-4..0.02), w={GUIDANCE_W}, "
                                    f"batch {B}/GPU (2x{B} UNet forwards per step), default UNet ch=128 ch_mult=[1,2,2,2] "
                                    "num_res_blocks=2 (47.8 M params), random-init weights, in-kernel Philox noise",
-                       "batch_per_gpu": B, "image": S, "launch": "hipGraph replay" if a.graph else "eager launches",
+                       "batch_per_gpu": B, "image": S, "launch": "plain launches" if a.eager else "hipGraph replay of the captured step",
+                       "ms_per_step_plain_launches_with_events": None if kernel_pass_s is None else kernel_pass_s * 1e3,
                        "sample_steps_per_s": world * K * B / elapsed,
                        "algorithmic_tflop_per_step_per_gpu": step_tflop,
                        "whole_step_tflops_per_gpu": step_tflop / (elapsed / K) if elapsed > 0 else None,

@@ -91,6 +91,7 @@ def train(modelConfig: Dict) -> List[float]:
     parallel.broadcast_parameters_(net.parameters())
     weights = list(net.parameters())
     opt = torch.optim.AdamW(weights, lr=cfg["lr"], weight_decay=WEIGHT_DECAY)
+    flat_grads = parallel.FlatGradients(weights, world) if world > 1 else None     # gradients as views of one exchange buffer
     schedule = GradualWarmupScheduler(
         optimizer=opt, multiplier=cfg["multiplier"], warm_epoch=cfg["epoch"] // 10,
         after_scheduler=torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=opt, T_max=cfg["epoch"], eta_min=0, last_epoch=-1))
@@ -111,10 +112,14 @@ def train(modelConfig: Dict) -> List[float]:
             labels = torch.as_tensor(domains).to(device) + 1
             if np.random.rand() < LABEL_DROP_PROBABILITY:          # one draw per batch, on the host, like the reference
                 labels = torch.zeros_like(labels)
-            opt.zero_grad()
+            if flat_grads is not None:
+                flat_grads.zero_()
+            else:
+                opt.zero_grad()
             loss = objective(x_0, labels).sum() / x_0.shape[0] ** 2.
             loss.backward()
-            parallel.allreduce_mean_grads_(weights)
+            if flat_grads is not None:
+                flat_grads.exchange_mean_()                        # the one collective of a step (mean over ranks)
             torch.nn.utils.clip_grad_norm_(weights, cfg["grad_clip"])
             opt.step()
             losses.append(loss.item())

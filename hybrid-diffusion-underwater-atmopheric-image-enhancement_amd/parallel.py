@@ -8,6 +8,8 @@ DDP with one process per GPU (utils/rotinas.py:572-577, 619).  The hot path shar
 * training: replicated weights, per-rank mini-batch, ONE exchange per optimizer step: the mean of the 47.8 M fp32
   gradients (190.8 MB).  On the MI355X node xGMI is a full mesh of point-to-point links, so the flat gradient buffer is
   reduced with reduce-scatter + all-gather (every link busy at once) rather than a ring all-reduce of small buckets.
+  The gradients live as views in that flat buffer (FlatGradients): no gather / scatter copies around the exchange.
+  NO scaling curve has been measured yet (the build box has one GPU; the driver's 8-GPU run was skipped in round 1).
 """
 from __future__ import annotations
 
@@ -60,12 +62,65 @@ def broadcast_parameters_(params: Iterable[torch.Tensor], src: int = 0) -> None:
             p.copy_(buf)      # an in-place write autograd sees: bumps p._version, so cached weight packs are refreshed
 
 
+def _exchange_mean_(flat: torch.Tensor, world: int) -> None:
+    """Mean over ranks of one flat fp32 buffer (numel divisible by world), in place: reduce-scatter + all-gather.
+    The same two collectives on every backend (RCCL on the GPUs, gloo in the CPU rehearsal): on the MI355X node xGMI is a
+    full mesh of point-to-point links, and a reduce-scatter / all-gather pair keeps all seven links of every GPU busy where
+    a ring all-reduce of small buckets is bound by one link."""
+    shard = torch.empty(flat.numel() // world, dtype=flat.dtype, device=flat.device)
+    dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+    shard.div_(world)
+    dist.all_gather_into_tensor(flat, shard)
+
+
+class FlatGradients:
+    """The gradients of a parameter list as views into ONE flat fp32 buffer, so that the per-step exchange of data-parallel
+    training (TrainCondition.train; the reference's other tree wraps its model in DDP, utils/rotinas.py:619) needs no gather /
+    scatter copies: autograd accumulates straight into the views, the exchange runs in place, the optimizer reads the views.
+
+        flat = FlatGradients(params)         # once
+        flat.zero_()                         # instead of optimizer.zero_grad(): zero the buffer, (re)attach p.grad
+        loss.backward(); flat.exchange_mean_(); clip_grad_norm_(params, ...); optimizer.step()
+    """
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], world: int | None = None):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        n = sum(p.numel() for p in self.params)
+        self.numel = n
+        padded = (n + self.world - 1) // self.world * self.world
+        dev = self.params[0].device if self.params else "cpu"
+        self.flat = torch.zeros(padded, dtype=torch.float32, device=dev)
+        self.views: List[torch.Tensor] = []
+        off = 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def zero_(self) -> None:
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v                      # parameters that receive no gradient this step contribute zeros
+
+    def exchange_mean_(self) -> int:
+        """Returns the bytes each rank contributes to the exchange (0 when there is nothing to exchange)."""
+        if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
+            return 0
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:             # someone replaced the view (e.g. optimizer.zero_grad(set_to_none=True))
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    v.copy_(p.grad)
+                p.grad = v
+        _exchange_mean_(self.flat, self.world)
+        return self.flat.numel() * 4
+
+
 def allreduce_mean_grads_(params: Sequence[torch.nn.Parameter]) -> int:
     """Average the gradients of `params` over all ranks in ONE flat fp32 buffer; returns the bytes exchanged per rank.
-
-    nccl/RCCL: reduce-scatter + all-gather on the flat buffer (full-mesh xGMI: all 7 links busy); gloo: all_reduce.
-    Parameters without a gradient contribute zeros (the reference's optimizer skips them identically on every rank).
-    """
+    One-shot form of :class:`FlatGradients` (gathers the gradients into a fresh flat buffer and scatters the means back);
+    parameters without a gradient contribute zeros (the reference's optimizer skips them identically on every rank)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
     world = dist.get_world_size()
@@ -81,14 +136,7 @@ def allreduce_mean_grads_(params: Sequence[torch.nn.Parameter]) -> int:
         if p.grad is not None:
             flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
         off += p.numel()
-    if dist.get_backend() == "nccl":
-        shard = torch.empty(padded // world, dtype=torch.float32, device=dev)
-        dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
-        shard.div_(world)
-        dist.all_gather_into_tensor(flat, shard)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(world)
+    _exchange_mean_(flat, world)
     off = 0
     for p in ps:
         g = flat[off:off + p.numel()].view_as(p)

@@ -18,6 +18,25 @@ def _free_port():
     return port
 
 
+def _plain(o):
+    """Tensors as numpy arrays: a tensor sent through the queue shares memory through a file descriptor that dies with the
+    worker, which may exit before the parent has read it."""
+    if torch.is_tensor(o):
+        return o.detach().numpy().copy()
+    if isinstance(o, (list, tuple)):
+        return type(o)(_plain(v) for v in o)
+    return o
+
+
+def _tensors(o):
+    import numpy as np
+    if isinstance(o, np.ndarray):
+        return torch.from_numpy(o)
+    if isinstance(o, (list, tuple)):
+        return type(o)(_tensors(v) for v in o)
+    return o
+
+
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -34,9 +53,25 @@ def _worker(rank, world, port, q):
     loss.backward()
     local = [None if p.grad is None else p.grad.clone() for p in params]
     nbytes = P.allreduce_mean_grads_(params)
+    # the training loop's form of the same exchange: gradients accumulated by autograd straight into views of one flat
+    # buffer, reduce-scatter + all-gather in place (the code path of the 8-GPU run: identical collectives on RCCL and gloo)
+    torch.manual_seed(7)                               # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+    unused = torch.nn.Parameter(torch.ones(3))
+    ps = list(net.parameters()) + [unused]
+    fg = P.FlatGradients(ps)
+    flat_results = []
+    for step in range(2):                              # two steps: the views must survive zero_() / backward / exchange
+        fg.zero_()
+        xb = torch.randn(4, 6, generator=torch.Generator().manual_seed(10 * step + rank))
+        net(xb).pow(2).sum().backward()
+        mine = [p.grad.clone() for p in ps]
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(fg.params, fg.views)), "autograd replaced a view"
+        sent = fg.exchange_mean_()
+        flat_results.append((mine, [p.grad.clone() for p in ps], sent))
     lo, hi = P.shard_range(11, world, rank)
     t = P.max_over_ranks(1.0 + rank)
-    q.put((rank, w0, local, [p.grad.clone() for p in params], nbytes, (lo, hi), t, P.rank_seed(5, rank)))
+    q.put(_plain((rank, w0, local, [p.grad.clone() for p in params], nbytes, (lo, hi), t, P.rank_seed(5, rank), flat_results)))
     dist.destroy_process_group()
 
 
@@ -47,11 +82,11 @@ def test_two_rank_gradient_exchange_and_sharding():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_tensors(q.get(timeout=120)) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, w0a, loc0, g0, nb0, s0, t0, seed0), (r1, w0b, loc1, g1, nb1, s1, t1, seed1) = res
+    (r0, w0a, loc0, g0, nb0, s0, t0, seed0, fr0), (r1, w0b, loc1, g1, nb1, s1, t1, seed1, fr1) = res
     assert torch.equal(w0a, w0b)                                       # broadcast made the replicas identical
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)                                       # every rank ends with the same averaged gradient
@@ -61,3 +96,26 @@ def test_two_rank_gradient_exchange_and_sharding():
     assert s0 == (0, 6) and s1 == (6, 11)                              # contiguous, balanced, exhaustive
     assert t0 == t1 == 2.0                                             # max over ranks
     assert seed0 != seed1
+    for (mine0, avg0, sent0), (mine1, avg1, sent1) in zip(fr0, fr1):
+        assert sent0 == sent1 and sent0 >= (6 * 5 + 5 + 5 * 2 + 2 + 3) * 4
+        for a, b, m0, m1 in zip(avg0, avg1, mine0, mine1):
+            assert torch.equal(a, b) and torch.allclose(a, (m0 + m1) / 2, atol=1e-7)
+        assert torch.equal(avg0[-1], torch.zeros(3))                   # a parameter outside the graph keeps a zero gradient
+
+
+def test_epoch_shards_are_disjoint_exhaustive_and_equal():
+    """TrainCondition._epoch_indices = DistributedSampler semantics (the reference's other tree: utils/rotinas.py:589-600):
+    per epoch one permutation shared by all ranks, padded to a multiple of the world size, dealt out strided."""
+    from hdiff_amd.DiffusionFreeGuidence.TrainCondition import _epoch_indices
+    for n, world in ((512, 8), (101, 8), (7, 2), (64, 1), (5, 8)):
+        for epoch in (0, 3):
+            shards = [_epoch_indices(n, epoch, r, world) for r in range(world)]
+            sizes = {len(s) for s in shards}
+            assert sizes == {(n + world - 1) // world}, (n, world, sizes)          # equal shards: no rank waits in the exchange
+            flat = [i for s in shards for i in s]
+            assert set(flat) == set(range(n))                                       # exhaustive
+            assert len(flat) - len(set(flat)) == (-n) % world if n >= world else True   # only the padding repeats
+            if n % world == 0:
+                assert len(set(flat)) == len(flat)                                  # disjoint
+        assert _epoch_indices(n, 0, 0, world) != _epoch_indices(n, 1, 0, world) or n < 3   # reshuffled every epoch
+        assert _epoch_indices(n, 2, 0, world) == _epoch_indices(n, 2, 0, world)            # deterministic
