@@ -100,6 +100,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void mha_bwd_fused_kernel(const Bwd
   constexpr int NV4 = 2 * D * (KT / 4);           // float4 of one staged Q + dO tile
   constexpr int NLD = (NV4 + ATT_THREADS - 1) / ATT_THREADS;
   constexpr bool OLD_EARLY = (MT == 1);
+  constexpr bool OPS_AHEAD = (MT == 1);           // operands of the next query subtile fetched during the current one
   constexpr bool KT_FENCE = (MT > 1);             // d_head 32: keep the key tiles' MFMA groups apart (register budget, see do_tile)
 
   __shared__ __attribute__((aligned(16))) float sQ[2][DP * KROW];
@@ -228,42 +229,61 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void mha_bwd_fused_kernel(const Bwd
     }
 
     // One staged query tile.  MASK: the key block holds keys >= L (their P must not reach dQ even as 0 * inf).
+    // operands of one 16-query subtile: A fragments of S / dP (query on the lane), of the accumulating products (channel
+    // on the lane, queries 4g..4g+3), and the row constants that enter as initial accumulators
+    struct QOps {
+      float qa[KS], doa[KS];
+      f32x4 qv[MT], dov[MT], nl, nd;
+    };
+    auto load_ops = [&](QOps& o, int buf, int qs) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        o.qa[s] = sQ[buf][(4 * s + g) * KROW + qs * 16 + i16];
+        o.doa[s] = sO[buf][(4 * s + g) * KROW + qs * 16 + i16];
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&sQ[buf][(mt * 16 + i16) * KROW + qs * 16 + 4 * g]);
+        const float4 b4 = *reinterpret_cast<const float4*>(&sO[buf][(mt * 16 + i16) * KROW + qs * 16 + 4 * g]);
+        o.qv[mt] = f32x4{a4.x, a4.y, a4.z, a4.w};
+        o.dov[mt] = f32x4{b4.x, b4.y, b4.z, b4.w};
+      }
+      // rows of the accumulators are queries 4g + r of this subtile: -lse2 / -delta enter as the initial accumulators
+      const float4 l4 = *reinterpret_cast<const float4*>(&sL[buf][qs * 16 + 4 * g]);
+      const float4 d4 = *reinterpret_cast<const float4*>(&sD[buf][qs * 16 + 4 * g]);
+      o.nl = f32x4{l4.x, l4.y, l4.z, l4.w};
+      o.nd = f32x4{d4.x, d4.y, d4.z, d4.w};
+    };
+
+    // One staged query tile.  MASK: the key block holds keys >= L (their P must not reach dQ even as 0 * inf).
     auto do_tile = [&](auto mask_tag, int buf, int dqbuf) {
       constexpr bool MASK = decltype(mask_tag)::value;
+      QOps ops[2];
+      if (OPS_AHEAD) load_ops(ops[0], buf, 0);
 #pragma unroll
       for (int qs = 0; qs < 4; ++qs) {
-        // keep the operand loads of one query subtile from being hoisted above the previous subtile's MFMAs (the scheduler
-        // otherwise holds the operands of all four subtiles live at once: 96 extra registers, one wave per SIMD)
+        // The scheduler must not hoist operand loads across subtiles on its own (it then holds the operands of all four
+        // live at once: 96 extra registers, one wave per SIMD).  d_head <= 16 has the registers to fetch ONE subtile ahead
+        // by hand, so that no subtile starts with an LDS round trip; d_head 32 loads them in place.
         __builtin_amdgcn_sched_barrier(0);
-        float qa[KS], doa[KS];
-        f32x4 qv[MT], dov[MT];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          qa[s] = sQ[buf][(4 * s + g) * KROW + qs * 16 + i16];
-          doa[s] = sO[buf][(4 * s + g) * KROW + qs * 16 + i16];
+        if (OPS_AHEAD) {
+          if (qs + 1 < 4) load_ops(ops[(qs + 1) & 1], buf, qs + 1);
+        } else {
+          load_ops(ops[qs & 1], buf, qs);
         }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const float4 a4 = *reinterpret_cast<const float4*>(&sQ[buf][(mt * 16 + i16) * KROW + qs * 16 + 4 * g]);
-          const float4 b4 = *reinterpret_cast<const float4*>(&sO[buf][(mt * 16 + i16) * KROW + qs * 16 + 4 * g]);
-          qv[mt] = f32x4{a4.x, a4.y, a4.z, a4.w};
-          dov[mt] = f32x4{b4.x, b4.y, b4.z, b4.w};
-        }
-        // rows of the accumulators are queries 4g + r of this subtile: -lse2 / -delta enter as the initial accumulators
-        const float4 l4 = *reinterpret_cast<const float4*>(&sL[buf][qs * 16 + 4 * g]);
-        const float4 d4 = *reinterpret_cast<const float4*>(&sD[buf][qs * 16 + 4 * g]);
-        const f32x4 nl = {l4.x, l4.y, l4.z, l4.w}, nd = {d4.x, d4.y, d4.z, d4.w};
+        __builtin_amdgcn_sched_barrier(0);
+        const QOps& o = ops[qs & 1];
         f32x4 dQa[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) dQa[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NK; ++kt) {
           if (KT_FENCE) __builtin_amdgcn_sched_barrier(0);
-          f32x4 S = nl, dP = nd;
+          f32x4 S = o.nl, dP = o.nd;
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
-            S = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], kreg[kt][s], S, 0, 0, 0);
-            dP = __builtin_amdgcn_mfma_f32_16x16x4f32(doa[s], vreg[kt][s], dP, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_16x16x4f32(o.qa[s], kreg[kt][s], S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_16x16x4f32(o.doa[s], vreg[kt][s], dP, 0, 0, 0);
           }
           f32x4 P, dS;
 #pragma unroll
@@ -288,8 +308,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void mha_bwd_fused_kernel(const Bwd
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              dV[mt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dov[mt][r], P[r], dV[mt][kt], 0, 0, 0);
-              dK[mt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[mt][r], dS[r], dK[mt][kt], 0, 0, 0);
+              dV[mt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.dov[mt][r], P[r], dV[mt][kt], 0, 0, 0);
+              dK[mt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.qv[mt][r], dS[r], dK[mt][kt], 0, 0, 0);
             }
 #pragma unroll
           for (int r = 0; r < 4; ++r)

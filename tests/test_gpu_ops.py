@@ -348,7 +348,7 @@ def test_q_sample_bit_exact_and_clip():
     lib, s = _capi.lib(), torch.cuda.current_stream().cuda_stream
     d_x0, d_nz, d_t = x0.to(DEV), nz.to(DEV), t.to(DEV)
     _capi.check(lib.hdiff_q_sample(d_x0.data_ptr(), d_nz.data_ptr(), d_t.data_ptr(), sa.data_ptr(),
-                                   sb.data_ptr(), out.data_ptr(), B, per, s))
+                                   sb.data_ptr(), out.data_ptr(), B, per, 8, s))
     assert torch.equal(out.cpu(), ref)
     big = torch.randn(1000, generator=g) * 3
     y = torch.empty(1000, device=DEV)
