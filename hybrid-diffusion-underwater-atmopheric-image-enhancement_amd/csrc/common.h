@@ -67,6 +67,11 @@ __device__ __forceinline__ TileId xcd_tile() {
   return TileId{(int)x, (int)(pair % gridDim.y), (int)(pair / gridDim.y)};
 }
 
+// conv_wgrad3x3.hip: the 3x3 / stride-1 weight-gradient kernel of the U-Net body (dispatched from conv_wgrad.hip)
+bool wgrad3x3_applicable(const hdiff_conv_wgrad_desc* d);
+int wgrad3x3_nsplit(const hdiff_conv_wgrad_desc* d);
+int launch_wgrad3x3(const hdiff_conv_wgrad_desc* d, float* dwp, int nsplit, hipStream_t stream);
+
 int contraction_mode();   // HDIFF_CONTRACT_*
 // attention_x3.hip: returns false when the shape is not covered (caller falls back to the fp32 kernels)
 bool launch_mha_fwd_x3(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, hipStream_t stream);
