@@ -195,7 +195,9 @@ class _FusedConv(Function):
         need_dx = need[0] or (ctx.has_x1 and need[1]) or (ctx.has_gn and (need[4] or need[5]))
         if need_dx:
             # dgrad: the forward kernel with flipped taps and the weight read as [GEMM-in = Cout][GEMM-out = Cin]
-            dtaps = E.TapSet([pad - ky for ky in taps.ky], [pad - kx for kx in taps.kx], taps.ky, taps.kx)
+            # taps listed in the forward's (dy, dx) order, each reading the mirrored kernel element: the same set of products
+            # as [pad - ky], and the order the specialised 3x3 kernels recognise
+            dtaps = E.TapSet(taps.dy, taps.dx, [pad - dy for dy in taps.dy], [pad - dx for dx in taps.dx])
             dA = torch.empty(B, cin, H, W, device=dev)
             _run_conv(dout, None, [(weight, 1, dtaps.ky, dtaps.kx, 0)], dtaps, cin, cout, None, dA, B=B, H=H, W=W, VH=H, VW=W)
             if ctx.dropped:
