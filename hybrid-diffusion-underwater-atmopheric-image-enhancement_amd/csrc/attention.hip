@@ -493,12 +493,13 @@ int launch_d(const float* qkv, float* o, float* lse2, int B, int C, int heads, i
   const float qscale = 1.4426950408889634f / sqrtf((float)D);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   int nq = (L >= 512) ? 4 : 1;   // 4 query tiles per wave: 3 waves per SIMD at d_head 16, 2 at d_head 32 (8 tiles measured no faster)
+  // d_head 32 on the fixed-reference kernel: 134 TFLOP/s against 120 on the running-max kernel (L = 16 384, batch 16)
   if (att_nq_override() > 0) nq = att_nq_override();
   if (nq == 4 && contraction_mode() == HDIFF_CONTRACT_BF16X3 &&
       launch_mha_fwd_x3(qkv, o, lse2, B, C, heads, L, qscale, stream)) {
     // split-bf16 kernel (attention_x3.hip), same fixed-reference protocol: overflow-proof fp32 kernel in check mode behind it
     launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, 1, stream);
-  } else if (nq == 4 && D <= 16 && L % KT == 0 && att_fast_enabled()) {   // d_head 32: 230 registers (2 waves/SIMD), measured no faster
+  } else if (nq == 4 && L % KT == 0 && att_fast_enabled()) {
     // fixed-reference fast kernel, then the overflow-proof kernel in check mode (exits at once unless flagged)
     dim3 grid(cdiv(L, 256), heads, B);
     hipLaunchKernelGGL((mha_flash_fwd_fast_kernel<D, 4>), grid, dim3(ATT_THREADS), 0, stream, qkv, o, lse2, C, L, qscale);
