@@ -492,21 +492,27 @@ template <int D>
 int launch_d(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, hipStream_t stream) {
   const float qscale = 1.4426950408889634f / sqrtf((float)D);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  int nq = (L >= 512) ? 4 : 1;   // 4 query tiles per wave: 3 waves per SIMD at d_head 16, 2 at d_head 32 (8 tiles measured no faster)
-  // d_head 32 on the fixed-reference kernel: 134 TFLOP/s against 120 on the running-max kernel (L = 16 384, batch 16)
-  if (att_nq_override() > 0) nq = att_nq_override();
-  if (nq == 4 && contraction_mode() == HDIFF_CONTRACT_BF16X3 &&
-      launch_mha_fwd_x3(qkv, o, lse2, B, C, heads, L, qscale, stream)) {
-    // split-bf16 kernel (attention_x3.hip), same fixed-reference protocol: overflow-proof fp32 kernel in check mode behind it
-    launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, 1, stream);
-  } else if (nq == 4 && L % KT == 0 && att_fast_enabled()) {
-    // fixed-reference fast kernel, then the overflow-proof kernel in check mode (exits at once unless flagged)
-    dim3 grid(cdiv(L, 256), heads, B);
-    hipLaunchKernelGGL((mha_flash_fwd_fast_kernel<D, 4>), grid, dim3(ATT_THREADS), 0, stream, qkv, o, lse2, C, L, qscale);
-    launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, 1, stream);
-  } else if (nq >= 8) launch_v<D, 8>(qkv, o, lse2, B, C, heads, L, qscale, 0, stream);
-  else if (nq >= 4) launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, 0, stream);
-  else launch_v<D, 1>(qkv, o, lse2, B, C, heads, L, qscale, 0, stream);
+  if constexpr (D >= 64) {
+    // d_head 64 (ch_mult containing 4 at ch = 128: C = 512): the running-max kernel with one query tile per wave -- the
+    // register budget of the wider tiles does not stretch to 16 k-steps; not a shape of the default model
+    launch_v<D, 1>(qkv, o, lse2, B, C, heads, L, qscale, 0, stream);
+  } else {
+    int nq = (L >= 512) ? 4 : 1;   // 4 query tiles per wave: 3 waves per SIMD at d_head 16, 2 at d_head 32 (8 tiles measured no faster)
+    // d_head 32 on the fixed-reference kernel: 134 TFLOP/s against 120 on the running-max kernel (L = 16 384, batch 16)
+    if (att_nq_override() > 0) nq = att_nq_override();
+    if (nq == 4 && contraction_mode() == HDIFF_CONTRACT_BF16X3 &&
+        launch_mha_fwd_x3(qkv, o, lse2, B, C, heads, L, qscale, stream)) {
+      // split-bf16 kernel (attention_x3.hip), same fixed-reference protocol: overflow-proof fp32 kernel in check mode behind it
+      launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, 1, stream);
+    } else if (nq == 4 && L % KT == 0 && att_fast_enabled()) {
+      // fixed-reference fast kernel, then the overflow-proof kernel in check mode (exits at once unless flagged)
+      dim3 grid(cdiv(L, 256), heads, B);
+      hipLaunchKernelGGL((mha_flash_fwd_fast_kernel<D, 4>), grid, dim3(ATT_THREADS), 0, stream, qkv, o, lse2, C, L, qscale);
+      launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, 1, stream);
+    } else if (nq >= 8) launch_v<D, 8>(qkv, o, lse2, B, C, heads, L, qscale, 0, stream);
+    else if (nq >= 4) launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, 0, stream);
+    else launch_v<D, 1>(qkv, o, lse2, B, C, heads, L, qscale, 0, stream);
+  }
   HDIFF_CHECK_LAUNCH("mha_flash_fwd_kernel");
   return HDIFF_OK;
 }
@@ -525,8 +531,9 @@ extern "C" int hdiff_mha_flash_fwd(const float* qkv, float* o, float* lse2, int 
     case 8: return launch_d<8>(qkv, o, lse2, B, C, heads, L, s);
     case 16: return launch_d<16>(qkv, o, lse2, B, C, heads, L, s);
     case 32: return launch_d<32>(qkv, o, lse2, B, C, heads, L, s);
+    case 64: return launch_d<64>(qkv, o, lse2, B, C, heads, L, s);
     default: break;
   }
-  hdiff::set_error("mha_flash_fwd: head dim %d not in {4, 8, 16, 32}", D);
+  hdiff::set_error("mha_flash_fwd: head dim %d not in {4, 8, 16, 32, 64}", D);
   return HDIFF_ERR_INVALID;
 }

@@ -129,7 +129,8 @@ def attention_ref(qkv, heads):
     return (w @ v).transpose(2, 3).reshape(B, Cc, H, W)
 
 
-@pytest.mark.parametrize("d,H,W,B", [(4, 8, 8, 2), (8, 6, 6, 2), (16, 16, 16, 1), (16, 32, 32, 1), (32, 24, 24, 1), (32, 5, 7, 1)])
+@pytest.mark.parametrize("d,H,W,B", [(4, 8, 8, 2), (8, 6, 6, 2), (16, 16, 16, 1), (16, 32, 32, 1), (32, 24, 24, 1), (32, 5, 7, 1),
+                                     (64, 16, 16, 1), (64, 5, 9, 2), (16, 72, 72, 1), (32, 80, 80, 1)])
 def test_flash_attention_backward(d, H, W, B):
     g = torch.Generator().manual_seed(d + H)
     Cc = 8 * d

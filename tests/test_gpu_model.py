@@ -231,3 +231,25 @@ def test_unet_edge_shapes_vs_oracle(B, H, W):
         out = s2(x.to(DEV), lab.to(DEV), noise_by_step=z.to(DEV))
         want = O.sampler_forward(sd, cfg, 1e-4, 0.02, 2, 0.0, x, lab, list(z))
         assert maxerr(out, want) < 2e-4
+
+
+def test_unet_with_d_head_64_vs_oracle():
+    """ch_mult containing 4 at ch = 128 gives C = 512 = 8 heads x d_head 64 (the reference accepts any ch_mult); forward
+    against the CPU oracle and one training step's gradients finite."""
+    torch.manual_seed(4)
+    cfgd = dict(T=10, num_labels=2, ch=128, ch_mult=[1, 4], num_res_blocks=1, dropout=0.0)
+    m = MC.UNet(**cfgd).eval()
+    cfg = O.UNetConfig(T=10, num_labels=2, ch=128, ch_mult=(1, 4), num_res_blocks=1)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 3, 16, 16, generator=g)
+    t, lab = torch.tensor([7]), torch.tensor([1])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.unet_forward(sd, cfg, x, t, lab)
+        md = m.to(DEV)
+        y = md(x.to(DEV), t.to(DEV), lab.to(DEV))
+    assert maxerr(y, ref) < 2e-4 * max(1.0, ref.abs().max().item())
+    md.train()
+    md(x.to(DEV), t.to(DEV), lab.to(DEV)).square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in md.named_parameters()
+               if "cond_embedding.condEmbedding.0" not in n)
