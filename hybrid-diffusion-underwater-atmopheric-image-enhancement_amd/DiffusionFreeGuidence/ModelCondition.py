@@ -17,7 +17,7 @@ from torch import nn
 
 from .. import engine as E
 
-__all__ = ["Swish", "TimeEmbedding", "ConditionalEmbedding", "DownSample", "UpSample", "ResBlock", "UNet"]
+__all__ = ["Swish", "TimeEmbedding", "ConditionalEmbedding", "DownSample", "UpSample", "AttnBlock", "ResBlock", "UNet"]
 
 
 def _params_of(mod: nn.Module, prefix: str = "") -> Dict[str, torch.Tensor]:
@@ -134,6 +134,31 @@ class UpSample(nn.Module, _EagerMixin):
         B, Cc, H, W = (int(v) for v in x.shape)
         plan = E.Plan(x.device)
         return self._finish(plan, E.emit_upsample(plan, _params_of(self, "m."), "m", x, B, Cc, H, W))
+
+
+class AttnBlock(nn.Module, _EagerMixin):
+    """GroupNorm -> 1x1 q, k, v -> softmax(q k^T * C^-1/2) v (ONE head of width in_ch) -> 1x1 proj -> x + h
+    (reference ModelCondition.py:92-120).  The reference's UNet never instantiates it (ResBlock uses
+    nn.MultiheadAttention instead, :189); it is provided because the module is part of the file's surface.  Inference only:
+    heads up to 64 channels wide run on the flash kernel, wider ones on a plain row-per-workgroup kernel."""
+
+    def __init__(self, in_ch):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(32, in_ch)
+        self.proj_q = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+        self.proj_k = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+        self.proj_v = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+        self.proj = nn.Conv2d(in_ch, in_ch, 1, stride=1, padding=0)
+
+    def forward(self, x):
+        x = _inputs(x=x)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("hdiff: AttnBlock (unused by the reference's UNet) runs inference only on the HIP path; "
+                                      "call it under torch.no_grad()")
+        B, Cc, H, W = (int(v) for v in x.shape)
+        with torch.cuda.device(x.device):
+            plan = E.Plan(x.device)
+            return self._finish(plan, E.emit_attn_block(plan, _params_of(self, "m."), "m", x, B, Cc, H, W))
 
 
 class ResBlock(nn.Module, _EagerMixin):

@@ -120,6 +120,17 @@ __global__ void gn_finalize_kernel(const float* __restrict__ ws, int B, int C, i
   }
 }
 
+// y = x * scale[b][c] + shift[b][c]: GroupNorm WITHOUT the Swish (the reference's AttnBlock normalises and projects,
+// ModelCondition.py:103-107; every other GroupNorm of the path is followed by Swish and fused into a conv prologue)
+__global__ void gn_affine_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, float* __restrict__ y, int HW) {
+  const int bc = blockIdx.x;
+  const float sc = scale[bc], sh = shift[bc];
+  const float* xp = x + (size_t)bc * HW;
+  float* yp = y + (size_t)bc * HW;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x) yp[i] = fmaf(xp[i], sc, sh);
+}
+
 __global__ void gn_swish_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                       const float* __restrict__ shift, float* __restrict__ y, int HW) {
   const int bc = blockIdx.x;   // plane index on x: B*C may exceed 65 535
@@ -165,5 +176,15 @@ extern "C" int hdiff_gn_swish_apply(const float* x, const float* scale, const fl
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   hipLaunchKernelGGL(gn_swish_apply_kernel, dim3(B * C, bx), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, HW);
   HDIFF_CHECK_LAUNCH("gn_swish_apply_kernel");
+  return HDIFF_OK;
+}
+
+extern "C" int hdiff_gn_affine_apply(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
+                                     hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(x && scale && shift && y, "gn_affine_apply: null pointer");
+  const int bx = cdiv(HW, 256) < 64 ? cdiv(HW, 256) : 64;
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(gn_affine_apply_kernel, dim3(B * C, bx), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, HW);
+  HDIFF_CHECK_LAUNCH("gn_affine_apply_kernel");
   return HDIFF_OK;
 }

@@ -324,6 +324,38 @@ def emit_mha(plan: Plan, P: Dict[str, torch.Tensor], p: str, h: torch.Tensor, B:
     return y
 
 
+def emit_attn_block(plan: Plan, P: Dict[str, torch.Tensor], p: str, x: torch.Tensor, B: int, Cc: int, H: int, W: int) -> torch.Tensor:
+    """AttnBlock.forward (ModelCondition.py:102-120): GroupNorm (no Swish) -> q, k, v as ONE stacked 1x1 conv -> single-head
+    attention of width C (scale C^-1/2) -> 1x1 proj with the residual x fused into its epilogue."""
+    L = H * W
+    scale, shift = plan.gn_scale_shift(x, None, P[f"{p}.group_norm.weight"], P[f"{p}.group_norm.bias"], B, L)
+    hn = plan.buf(B, Cc, H, W)
+    plan.call("hdiff_gn_affine_apply", x.data_ptr(), scale.data_ptr(), shift.data_ptr(), hn.data_ptr(), B, Cc, L)
+    plan.keep((x, scale, shift, hn))
+    plan.free(scale); plan.free(shift)
+    # rows [Wq | Wk | Wv]: the layout the attention kernels read (same as nn.MultiheadAttention's packed in-projection)
+    w_qkv = torch.cat([P[f"{p}.proj_q.weight"], P[f"{p}.proj_k.weight"], P[f"{p}.proj_v.weight"]], dim=0).detach().contiguous()
+    b_qkv = torch.cat([P[f"{p}.proj_q.bias"], P[f"{p}.proj_k.bias"], P[f"{p}.proj_v.bias"]], dim=0).detach().contiguous()
+    plan.keep((w_qkv, b_qkv))
+    pk_in = _std_pack(plan, w_qkv, 1, 0)
+    qkv = plan.buf(B, 3 * Cc, H, W)
+    plan.conv(hn, None, pk_in, b_qkv, qkv, B=B, H=H, W=W, VH=H, VW=W)
+    plan.free(hn)
+    o = plan.buf(B, Cc, H, W)
+    if Cc <= 64:
+        plan.call("hdiff_mha_flash_fwd", qkv.data_ptr(), o.data_ptr(), None, B, Cc, 1, L)      # one head of width C
+    else:
+        plan.call("hdiff_mha_wide_fwd", qkv.data_ptr(), o.data_ptr(), B, Cc, L)
+    plan.flops += 4.0 * L * L * Cc * B
+    plan.keep((qkv, o))
+    plan.free(qkv)
+    pk_out = _std_pack(plan, P[f"{p}.proj.weight"], 1, 0)
+    y = plan.buf(B, Cc, H, W)
+    plan.conv(o, None, pk_out, P[f"{p}.proj.bias"], y, B=B, H=H, W=W, VH=H, VW=W, residual=x)
+    plan.free(o)
+    return y
+
+
 def emit_resblock(plan: Plan, P: Dict[str, torch.Tensor], p: str, xa: torch.Tensor, xb: Optional[torch.Tensor],
                   temb: torch.Tensor, cemb: Optional[torch.Tensor], cout: int, B: int, H: int, W: int, attn: bool) -> torch.Tensor:
     """ResBlock.forward (ModelCondition.py:196-211) on the virtual concat [xa | xb]."""

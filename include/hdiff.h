@@ -154,6 +154,9 @@ int hdiff_gn_swish_bwd(const float* x0, const float* x1, int C0, int C1, int B, 
                        float* dx1, float* dgamma, float* dbeta, hdiff_stream_t stream);
 /* dvec[b][c] = sum_hw dy[b][c][:] (gradient of the per-sample channel vector) and dbias[c] = sum_b dvec[b][c]; either may be NULL */
 int hdiff_bias_addvec_grad(const float* dy, int B, int C, int HW, float* dvec, float* dbias, hdiff_stream_t stream);
+/* y = x*scale[b][c] + shift[b][c]: GroupNorm without Swish (AttnBlock, ModelCondition.py:103) */
+int hdiff_gn_affine_apply(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
+                          hdiff_stream_t stream);
 /* Stand-alone y = swish(x*scale+shift) (used by tests and by the training path). */
 int hdiff_gn_swish_apply(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
                          hdiff_stream_t stream);
@@ -166,6 +169,10 @@ int hdiff_gn_swish_apply(const float* x, const float* scale, const float* shift,
  * ------------------------------------------------------------------------------------------------------------------ */
 int hdiff_mha_flash_fwd(const float* qkv, float* o, float* lse2 /*[B][heads][L] or NULL*/, int B, int C, int heads, int L,
                         hdiff_stream_t stream);
+/* Single-head attention with a head wider than 64 channels: softmax(q k^T * C^-1/2) v with d_head = C, the core of the
+ * reference's AttnBlock (ModelCondition.py:109-116; dead code there, built for completeness: one workgroup per query row,
+ * L + C floats of LDS).  qkv [B][3C][L] rows [q | k | v], o [B][C][L].  Heads of width <= 64: hdiff_mha_flash_fwd, heads = 1. */
+int hdiff_mha_wide_fwd(const float* qkv, float* o, int B, int C, int L, hdiff_stream_t stream);
 /* Backward of the core (autograd of nn.MultiheadAttention, TrainCondition.py:60): dqkv [B][3C][L] from dO [B][C][L].
  * lse2 is the forward's log2-domain log-sum-exp; delta is a [B][heads][L] workspace (rowsum(dO o O), written here).
  * P is recomputed, never stored; five MFMA products per tile in ONE kernel: a workgroup owns a key range (dK, dV in

@@ -160,6 +160,20 @@ def mha_self_attention(x_lbc: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor,
     return o @ out_w.t() + out_b
 
 
+def attn_block(sd: SD, p: str, x: Tensor) -> Tensor:
+    """AttnBlock.forward, ModelCondition.py:102-120 (dead code in the reference's UNet): GroupNorm(32) WITHOUT Swish, 1x1
+    q / k / v, w = softmax(q^T k * C^-1/2) over all positions (one head of width C), h = w v, 1x1 proj, x + h."""
+    B, C, H, W = x.shape
+    h = group_norm(x, 32, sd[f"{p}.group_norm.weight"], sd[f"{p}.group_norm.bias"], 1e-5)
+    conv1 = lambda name: torch.nn.functional.conv2d(h, sd[f"{p}.{name}.weight"], sd[f"{p}.{name}.bias"])
+    q = conv1("proj_q").permute(0, 2, 3, 1).reshape(B, H * W, C)
+    k = conv1("proj_k").reshape(B, C, H * W)
+    v = conv1("proj_v").permute(0, 2, 3, 1).reshape(B, H * W, C)
+    w = torch.softmax(torch.bmm(q, k) * (int(C) ** (-0.5)), dim=-1)
+    o = torch.bmm(w, v).reshape(B, H, W, C).permute(0, 3, 1, 2)
+    return x + torch.nn.functional.conv2d(o, sd[f"{p}.proj.weight"], sd[f"{p}.proj.bias"])
+
+
 def res_block(sd: SD, p: str, x: Tensor, temb: Tensor, cemb: Tensor, cfg: UNetConfig, attn: bool,
               training: bool = False, drop_mask: Optional[Tensor] = None) -> Tensor:
     """ResBlock.forward, ModelCondition.py:196-211.

@@ -11,6 +11,8 @@ data only; they travel to the GPU box, the reference does not.
 Fixtures:
   G1 schedules.npz        Trainer/Sampler float64 buffers for three (beta_1, beta_T, T)
   G2 modules.npz          Swish, TimeEmbedding, ConditionalEmbedding, DownSample, UpSample, ResBlock x3 (+weights)
+  G2b attnblock.npz       AttnBlock (dead code in the reference's UNet) at 64 channels (flash path) and 128 (wide-head path)
+                          [python -m oracle.gen_golden g2b]
   G3 unet_small.npz       small UNet (ch=32, ch_mult=[1,2], nrb=1): state_dict, inputs, eps @16^2 and @32^2, per-layer taps
   G4 unet_default64.npz   default UNet (ch=128,[1,2,2,2],nrb=2) @64^2 B=1: seed recipe, weight checksums, input, eps
   G4b unet_default128.npz default UNet @128^2 B=1 (BASELINE config C2's shape; the reference materialises 8 x 16384^2 scores
@@ -147,6 +149,23 @@ def gen_modules(RM):
         out[f"{name}/meta"] = np.array([cin, cout, int(attn), hw])
         out.update(_sd_np(rb.state_dict(), f"{name}/sd/"))
     np.savez_compressed(os.path.join(OUT, "modules.npz"), **out)
+
+
+def gen_attnblock(RM):
+    g = torch.Generator().manual_seed(17)
+    out = {}
+    for name, (cin, hw) in {"c64": (64, 12), "c128": (128, 10)}.items():
+        torch.manual_seed(40 + cin)
+        ab = RM.AttnBlock(cin).eval()
+        with torch.no_grad():
+            ab.group_norm.weight.add_(torch.randn(cin, generator=g) * 0.2)      # default affine is the identity: exercise it
+            ab.group_norm.bias.add_(torch.randn(cin, generator=g) * 0.2)
+        x = torch.randn(2, cin, hw, hw + 1, generator=g) * 1.5
+        with torch.no_grad():
+            out[f"{name}/x"], out[f"{name}/y"] = _np(x), _np(ab(x))
+        out[f"{name}/meta"] = np.array([cin, hw, hw + 1])
+        out.update(_sd_np(ab.state_dict(), f"{name}/sd/"))
+    np.savez_compressed(os.path.join(OUT, "attnblock.npz"), **out)
 
 
 def _small_model(RM):
@@ -356,6 +375,9 @@ def main():
     RD, RM = RL.load_diffusion(), RL.load_model()
     if len(sys.argv) > 1 and sys.argv[1] == "g4b":      # the large fixture alone (minutes, ~25 GB of host memory)
         gen_unet_default128(RM)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g2b":
+        gen_attnblock(RM)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g5b":
         gen_sampler_default128(RM, RD)

@@ -253,3 +253,21 @@ def test_unet_with_d_head_64_vs_oracle():
     md(x.to(DEV), t.to(DEV), lab.to(DEV)).square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in md.named_parameters()
                if "cond_embedding.condEmbedding.0" not in n)
+
+
+def test_attn_block_against_golden():
+    """AttnBlock: one head as wide as the block (64 channels -> flash kernel with heads = 1; 128 -> the wide-head kernel),
+    GroupNorm without Swish, residual; against the reference's recorded outputs."""
+    d = load("attnblock.npz")
+    for name in ("c64", "c128"):
+        cin = int(d[f"{name}/meta"][0])
+        ab = MC.AttnBlock(cin)
+        ab.load_state_dict(sd_from(d, f"{name}/sd/"), strict=True)
+        ab = ab.to(DEV).eval()
+        with torch.no_grad():
+            y = ab(T(d[f"{name}/x"]).to(DEV))
+        e = maxerr(y, T(d[f"{name}/y"]))
+        print(f"AttnBlock {name}: max err {e:.3e}")
+        assert e < 5e-5, (name, e)
+    with pytest.raises(NotImplementedError):
+        ab.train()(T(d["c128/x"]).to(DEV))          # inference only (dead code in the reference)

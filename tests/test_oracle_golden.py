@@ -63,6 +63,15 @@ def test_modules():
         assert torch.allclose(y, T(d[f"{name}/y"]), atol=5e-6), name
 
 
+def test_attn_block_oracle_against_the_reference():
+    """AttnBlock (ModelCondition.py:92-120, never instantiated by the reference's UNet): oracle vs the reference's outputs."""
+    d = load("attnblock.npz")
+    for name in ("c64", "c128"):
+        sd = {"p." + k: v for k, v in sd_from(d, f"{name}/sd/").items()}
+        y = O.attn_block(sd, "p", T(d[f"{name}/x"]))
+        assert torch.allclose(y, T(d[f"{name}/y"]), atol=5e-6), name
+
+
 def small_cfg(d):
     c = json.loads(bytes(d["cfg_json"]).decode())
     return O.UNetConfig(T=c["T"], num_labels=c["num_labels"], ch=c["ch"], ch_mult=tuple(c["ch_mult"]),
