@@ -9,8 +9,9 @@ driven by the same config dict (keys of MainCondition.py:5-29) with the same loo
          noisy and sampled grids saved as PNG (x*0.5+0.5)                                             [reference :75-108]
 
 Differences: the data set.  The reference hard-codes torchvision CIFAR10; here ``modelConfig["dataset"]`` selects
-"folder" (``data_dir/<domain>/*.png``: clean image = x_0, domain index = label), "synthetic", or "cifar10" (only if
-torchvision is installed).  Optional keys, all with reference-equivalent defaults: ``num_labels`` (10), ``num_workers`` (4),
+"folder" (``data_dir/<domain>/*.png``: clean image = x_0, domain index = label), "reference_sets" (the reference's own
+``data/`` tree of underwater / atmospheric sets, ``hdiff_amd.datasets``), "synthetic", or "cifar10" (only if torchvision is
+installed).  Optional keys, all with reference-equivalent defaults: ``num_labels`` (10), ``num_workers`` (4),
 ``max_steps_per_epoch``.  Under ``torch.distributed.run`` (WORLD_SIZE > 1) training is data-parallel: replicated weights,
 per-rank shard of every epoch, ONE mean all-reduce of the gradients per step (hdiff_amd.parallel), rank-0 checkpoints.
 """
@@ -44,6 +45,18 @@ def _dataset(cfg: Dict):
         return ImageDomainFolder(cfg["data_dir"], cfg["img_size"])
     if kind == "synthetic":
         return SyntheticDomains(cfg.get("synthetic_size", 512), cfg["img_size"], cfg.get("num_labels", 10))
+    if kind == "reference_sets":
+        # the reference's own data/ tree (utils/utils.py:309-473): reference images of the named underwater and / or
+        # atmospheric sets, label = 0 for underwater, 1 for atmospheric
+        from ..datasets import Atmospheric_Dataset, ReferenceImagesWithDomain, Underwater_Dataset
+        sets = []
+        if cfg.get("underwater_dataset"):
+            sets.append(Underwater_Dataset(cfg["underwater_dataset"], task="train", root=cfg.get("underwater_root")))
+        if cfg.get("atmospheric_dataset"):
+            sets.append(Atmospheric_Dataset(cfg["atmospheric_dataset"], task="train", root=cfg.get("atmospheric_root")))
+        if not sets:
+            raise ValueError("dataset 'reference_sets' needs underwater_dataset and / or atmospheric_dataset")
+        return ReferenceImagesWithDomain(sets, cfg["img_size"])
     if kind == "cifar10":
         from torchvision import transforms
         from torchvision.datasets import CIFAR10
