@@ -82,10 +82,28 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   // ---- per-thread staging slots, fixed for the whole kernel (the patch geometry is the same for every chunk)
   int x_soff[NXS];     // ci*H*W + iy*W + ix inside the chunk's first plane, or -1 when the position is zero padding
   int x_meta[NXS];     // LDS float offset | ci << 24
-  {
-    // SPEC: the patch is (8 + 2) x (32 + 2) -- divisions by compile-time constants
-    const int plane_elems = SPEC ? 340 : p.PH * p.PW;
-    const int pw = SPEC ? 34 : p.PW;
+  // SPEC: every staging thread serves ONE channel of the chunk (32 threads per channel, elements m = tid % 32 + 32 i of its
+  // 340-element patch), so the per-slot state is an image offset and an LDS offset, the "outside the image" test is one bit
+  // of a mask, and the GroupNorm scale / shift of the thread are two registers per chunk.  (PMC, round 2: the generic slot
+  // scheme below costs 2.3 VALU instructions per MFMA -- 13 % of the kernel's time, all of it taken from the matrix pipe.)
+  const int s_ci = tid >> 5;
+  unsigned s_out = 0;  // SPEC: bit i: slot i is zero padding (outside the image) -- its load goes to a safe offset
+  if constexpr (SPEC == 1) {
+    const int safe = vy0 * p.W + vx0;
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      const int m = (tid & 31) + 32 * i;
+      const int py = m / 34, px = m - py * 34;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool in_patch = m < 340;
+      const bool in_img = in_patch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      x_soff[i] = in_img ? iy * p.W + ix : safe;
+      x_meta[i] = in_patch ? s_ci * 350 + py * 35 + px : -1;
+      s_out |= (in_img ? 0u : 1u) << i;
+    }
+  } else {
+    const int plane_elems = p.PH * p.PW;
+    const int pw = p.PW;
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
       const int e = tid + i * NTHREADS;
@@ -134,14 +152,23 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
 
   float xr[NXS];
   float4 wr[NWS];
+  unsigned s_dead = 0;   // SPEC: all ones when this thread's channel of the chunk in flight does not exist (Cin % 8 != 0)
   auto issue_loads = [&](int c0) {
     // a chunk never straddles the concat seam (C0 % CK == 0 is checked on the host)
     const float* xbase = (c0 < p.C0) ? p.x0 + ((size_t)b * p.C0 + c0) * HW : p.x1 + ((size_t)b * p.C1 + (c0 - p.C0)) * HW;
     const int c_left = p.Cin - c0;     // channels of this chunk that exist
+    if constexpr (SPEC == 1) {
+      const bool live = s_ci < c_left;
+      s_dead = live ? 0u : ~0u;
+      const float* xs = xbase + (size_t)(live ? s_ci : 0) * HW;        // a missing channel reads channel 0 and is zeroed
 #pragma unroll
-    for (int i = 0; i < NXS; ++i) {
-      const bool ok = x_soff[i] >= 0 && (x_meta[i] >> 24) < c_left;
-      xr[i] = ok ? xbase[x_soff[i]] : 0.f;
+      for (int i = 0; i < NXS; ++i) xr[i] = xs[x_soff[i]];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NXS; ++i) {
+        const bool ok = x_soff[i] >= 0 && (x_meta[i] >> 24) < c_left;
+        xr[i] = ok ? xbase[x_soff[i]] : 0.f;
+      }
     }
     const float* wbase = p.wp + (size_t)c0 * p.CoutPad + co0;
 #pragma unroll
@@ -150,13 +177,30 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   };
   auto store_staged = [&](int c0) {
     const int c_left = p.Cin - c0;
+    if constexpr (SPEC == 1) {
+      float gsc = 1.f, gsh = 0.f;
+      if (has_gn && s_ci < c_left) {
+        gsc = sG[c0 + s_ci];
+        gsh = sG[p.Cin + c0 + s_ci];
+      }
+      const unsigned zero = s_out | s_dead;
 #pragma unroll
-    for (int i = 0; i < NXS; ++i) {
-      if (x_meta[i] >= 0) {
-        float v = xr[i];
-        const int ci = x_meta[i] >> 24;
-        if (has_gn && x_soff[i] >= 0 && ci < c_left) v = swish_fast(fmaf(v, sG[c0 + ci], sG[p.Cin + c0 + ci]));
-        sX[x_meta[i] & 0xFFFFFF] = v;
+      for (int i = 0; i < NXS; ++i) {
+        if (x_meta[i] >= 0) {
+          float v = xr[i];
+          if (has_gn) v = swish_fast(fmaf(v, gsc, gsh));
+          sX[x_meta[i]] = ((zero >> i) & 1u) ? 0.f : v;               // the conv pads the ACTIVATED tensor with zeros
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NXS; ++i) {
+        if (x_meta[i] >= 0) {
+          float v = xr[i];
+          const int ci = x_meta[i] >> 24;
+          if (has_gn && x_soff[i] >= 0 && ci < c_left) v = swish_fast(fmaf(v, sG[c0 + ci], sG[p.Cin + c0 + ci]));
+          sX[x_meta[i] & 0xFFFFFF] = v;
+        }
       }
     }
 #pragma unroll
