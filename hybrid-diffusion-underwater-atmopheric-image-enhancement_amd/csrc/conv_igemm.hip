@@ -232,6 +232,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
     };
     if constexpr (SPEC == 1) {
       constexpr int PWP = 35, PL = 350;          // (8 + 2) x (32 + 2) patch, odd row stride
+      // Every operand read below is ONE ds_read_b32 with an immediate offset from its own base register.  The bases are made
+      // opaque to the compiler on purpose: when it can relate two of them it fuses the reads into ds_read2_b32, whose 8-bit
+      // offsets do not reach across the slab, and pays one v_add per pair to rebase -- VALU issue time that the fp32 MFMA
+      // stream cannot overlap (2-3 such adds per k-step in round 1's build).
+      int wo0 = 0, wo1 = 32, xo_[WN];
+      asm volatile("" : "+v"(wo0));
+      asm volatile("" : "+v"(wo1));
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) {
+        xo_[nt] = pixoff[nt];
+        asm volatile("" : "+v"(xo_[nt]));
+      }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
@@ -240,8 +252,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
           const int wo = (tap * CK + 2 * k2) * BM;
           float bf[WN];
 #pragma unroll
-          for (int nt = 0; nt < WN; ++nt) bf[nt] = sXh[pixoff[nt] + xo];
-          mma(sWh[wo], sWh[wo + 32], bf);
+          for (int nt = 0; nt < WN; ++nt) bf[nt] = sXh[xo_[nt] + xo];
+          mma(sWh[wo0 + wo], sWh[wo1 + wo], bf);
         }
       }
     } else {

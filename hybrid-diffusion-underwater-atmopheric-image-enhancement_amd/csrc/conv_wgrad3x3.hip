@@ -159,6 +159,11 @@ __global__ __launch_bounds__(FT) void conv_wgrad3x3_kernel(const WgradF p) {
     const float* sX = sY + SY_FLOATS;
     const float* ya = sY + h * YS + wave * 32 + l31;          // A: dY[pixel 2 kk + h][co]
     const float* xb = sX + l31 * XP + h;                       // B: patch[ci][row + ky][column 2 kk' + h + kx]
+    // one base register per tap column, opaque to the compiler: each read stays a ds_read_b32 with an immediate offset
+    // (related bases get fused into ds_read2_b32 whose short offsets cost a v_add per pair -- VALU time the MFMAs cannot hide)
+    int bo[3] = {0, 1, 2};
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) asm volatile("" : "+v"(bo[kx]));
 #pragma unroll
     for (int kk = 0; kk < FP / 2; ++kk) {
       const int row = kk >> 4, col = 2 * (kk & 15);
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(FT) void conv_wgrad3x3_kernel(const WgradF p) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - 3 * ky;
-        const float bv = xb[(row + ky) * PC + col + kx];
+        const float bv = xb[bo[kx] + (row + ky) * PC + col];
         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[tap], 0, 0, 0);
       }
     }

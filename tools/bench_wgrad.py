@@ -21,7 +21,8 @@ for (cin, cout, S, gn) in [(128, 128, 256, True), (384, 128, 256, True), (256, 2
 
     def run():
         A._run_wgrad(x, None, g, dy, taps, cout, cin, B=B, H=S, W=S, VH=S, VW=S, targets=[(dw, 0, taps.ky, taps.kx, 0)])
-    run()
+    for _ in range(5):          # warm-up (the first shape otherwise pays the clock ramp of an idle GPU)
+        run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
