@@ -278,44 +278,42 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
     __syncthreads();
   }
 
-  // ---- epilogue: + bias + per-sample channel vector + residual, NCHW store (32 consecutive pixels per register row)
+  // ---- epilogue: + bias + per-sample channel vector + residual, NCHW store (32 consecutive pixels per register row).
+  // Address arithmetic is kept out of the per-element path: one 64-bit base per (pixel tile, tensor), then 32-bit element
+  // offsets that advance by the plane size from one accumulator register to the next (the channel rows of a 32x32 tile are
+  // 0,1,2,3, 8,9,10,11, ... + 4h).  Round 2's ISA count of the previous form (a 64-bit multiply-add chain and a bounds test per
+  // element) was ~25 VALU instructions per output element -- 0.7 per MFMA of a 128-channel conv, none of it overlappable.
+  const bool full_block = (co0 + BM <= p.Cout);      // every channel row of the block exists (all but the 3-channel tail conv)
+  const int co_lim = p.Cout - co0;
 #pragma unroll
   for (int nt = 0; nt < WN; ++nt) {
     const int pidx = (wave * WN + nt) * 32 + l31;
     const int vy = vy0 + (pidx >> p.tw_log2), vx = vx0 + (pidx & TWm1);
     if (vy >= p.VH || vx >= p.VW) continue;
-    if (p.ksplit > 1) {
-      // split-K: raw partial sums over this slice's channels, compact [kslice][b][co][virtual pixel]
-      const size_t vplane = (size_t)p.VH * p.VW;
-      float* dst = p.partial + (((size_t)kslice * p.B + b) * p.Cout) * vplane + (size_t)vy * p.VW + vx;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        if (mt == 1 && !two_m) break;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (co < p.Cout) dst[(size_t)co * vplane] = acc[mt][nt][r];
-        }
-      }
-      continue;
-    }
-    const int oy = vy * p.out_sy + p.out_oy, ox = vx * p.out_sx + p.out_ox;
-    const size_t pix = (size_t)oy * p.OW + ox;
-    const size_t plane = (size_t)p.OH * p.OW;
+    const bool split = p.ksplit > 1;
+    // split-K: raw partial sums over this slice's channels, compact [kslice][b][co][virtual pixel]
+    const int plane = split ? p.VH * p.VW : p.OH * p.OW;                    // < 2^25 (checked on the host): 64 rows fit 32 bits
+    const int pix = split ? vy * p.VW + vx : (vy * p.out_sy + p.out_oy) * p.OW + (vx * p.out_sx + p.out_ox);
+    const size_t blk = ((split ? (size_t)kslice * p.B + b : (size_t)b) * p.Cout + co0) * (size_t)plane + pix;
+    float* obase = (split ? p.partial : p.out) + blk;
+    const float* rbase = (!split && p.residual) ? p.residual + blk : nullptr;
+    const float* bias_h = (!split && p.bias) ? p.bias + co0 + 4 * h : nullptr;
+    const float* vec_h = (!split && p.addvec) ? p.addvec + (size_t)b * p.Cout + co0 + 4 * h : nullptr;
+    int rel = 4 * h * plane;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       if (mt == 1 && !two_m) break;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < p.Cout) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2);                   // + 4h: the channel row inside the block
+        if (full_block || row + 4 * h < co_lim) {
           float v = acc[mt][nt][r];
-          if (p.bias) v += p.bias[co];
-          if (p.addvec) v += p.addvec[b * p.Cout + co];
-          const size_t o = ((size_t)b * p.Cout + co) * plane + pix;
-          if (p.residual) v += p.residual[o];
-          p.out[o] = v;
+          if (bias_h) v += bias_h[row];
+          if (vec_h) v += vec_h[row];
+          if (rbase) v += rbase[rel];
+          obase[rel] = v;
         }
+        rel += ((r & 3) == 3) ? 5 * plane : plane;                           // next register: +1 row, or +5 rows after every fourth
       }
     }
   }
@@ -446,6 +444,8 @@ int configure(const hdiff_conv_desc* d, ConvCfg& c) {
   HDIFF_CHECK_ARG((d->VH - 1) * d->out_sy + d->out_oy < d->OH && (d->VW - 1) * d->out_sx + d->out_ox < d->OW,
                   "conv2d_fwd: virtual grid maps outside the output tensor");
   HDIFF_CHECK_ARG((d->gn_scale == nullptr) == (d->gn_shift == nullptr), "conv2d_fwd: gn_scale/gn_shift must come together");
+  HDIFF_CHECK_ARG((long)d->OH * d->OW < (1L << 25) && (long)d->VH * d->VW < (1L << 25),
+                  "conv2d_fwd: planes of 2^25 pixels or more are not supported (32-bit element offsets inside a channel block)");
 
   ConvK& k = c.k;
   k = ConvK{};
