@@ -71,6 +71,9 @@ __device__ __forceinline__ TileId xcd_tile() {
 bool wgrad3x3_applicable(const hdiff_conv_wgrad_desc* d);
 int wgrad3x3_nsplit(const hdiff_conv_wgrad_desc* d);
 int launch_wgrad3x3(const hdiff_conv_wgrad_desc* d, float* dwp, int nsplit, hipStream_t stream);
+bool wgrad1x1_applicable(const hdiff_conv_wgrad_desc* d);     // same file: the 1x1 / stride-1 convs without a prologue
+int wgrad1x1_nsplit(const hdiff_conv_wgrad_desc* d);
+int launch_wgrad1x1(const hdiff_conv_wgrad_desc* d, float* dwp, int nsplit, hipStream_t stream);
 
 int contraction_mode();   // HDIFF_CONTRACT_*
 // attention_x3.hip: returns false when the shape is not covered (caller falls back to the fp32 kernels)

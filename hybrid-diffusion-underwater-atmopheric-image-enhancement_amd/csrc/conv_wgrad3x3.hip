@@ -192,9 +192,165 @@ __global__ __launch_bounds__(FT) void conv_wgrad3x3_kernel(const WgradF p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 1x1 / stride-1 weight gradients (the attention in / out projections and the ResBlock shortcuts: a quarter of the conv FLOPs
+// at the attention levels; the generic kernel ran them at 6 VALU instructions per MFMA, 40 % MFMA busy):
+//     dW[co][ci] = sum_{b, p} dY[b][co][p] * X[b][ci][p]                      -- a plain GEMM with K = pixels
+// Same schedule as the 3x3 kernel above with channel GROUPS in place of taps: M = 128 output channels (4 waves x 32 rows),
+// N = 128 input channels = four 32-channel N tiles, K = 64 consecutive pixels of the flattened plane per tile.  dY and X tiles
+// have the same shape and are staged by the same code (16-byte loads, pixel-major [64 px][129] in LDS: A and B operands of lane
+// l31 at pixel p are conflict-free), double-buffered, one barrier per tile.  No GroupNorm prologue exists on these convs.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int P1 = 64;                 // pixels per tile
+constexpr int T1_FLOATS = P1 * YS;     // one staged tile: [64 px][129]
+constexpr int N1 = 8;                  // float4 loads per thread per tile and tensor (128 rows x 16 segments / 256)
+
+struct Wgrad1 {
+  const float* x0;
+  const float* x1;
+  int C0, C1, Cin;
+  const float* dy;
+  int Cout, HW, tiles_per_image, total_tiles, nsplit, CinPad, CoutPad;
+  float* dwp;
+};
+
+__global__ __launch_bounds__(FT) void conv_wgrad1x1_kernel(const Wgrad1 p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int co0 = blockIdx.x * FM;
+  const int ci0 = blockIdx.y * 128;
+  const int split = blockIdx.z;
+  const size_t HW = (size_t)p.HW;
+
+  // staging: float4 number idx = tid + 256 i -> row (channel) idx / 16 = tid / 16 + 16 i, pixels 4 (tid % 16) ..+3
+  const int srow = tid >> 4, sc4 = tid & 15;
+  const float* xrow[N1];       // this thread's eight input-channel rows (sample 0), nullptr-free: missing channels read row 0
+  size_t xbs[N1];              // their batch strides (x0 and x1 have different channel counts)
+  unsigned xdead = 0;          // bit i: channel ci0 + row does not exist (Cin not a multiple of 128): staged as zero
+#pragma unroll
+  for (int i = 0; i < N1; ++i) {
+    const int c = ci0 + srow + 16 * i;
+    const bool live = c < p.Cin;
+    const int cc = live ? c : 0;
+    xrow[i] = (cc < p.C0) ? p.x0 + (size_t)cc * HW : p.x1 + (size_t)(cc - p.C0) * HW;
+    xbs[i] = (size_t)((cc < p.C0) ? p.C0 : p.C1) * HW;
+    xdead |= (live ? 0u : 1u) << i;
+  }
+  const float* yrow0 = p.dy + (size_t)(co0 + srow) * HW;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+  float4 xr[N1], yr[N1];
+  auto issue_loads = [&](int t) {
+    const int b = t / p.tiles_per_image;
+    const size_t p0 = (size_t)(t - b * p.tiles_per_image) * P1 + sc4 * 4;
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      xr[i] = *reinterpret_cast<const float4*>(xrow[i] + (size_t)b * xbs[i] + p0);
+      yr[i] = *reinterpret_cast<const float4*>(yrow0 + ((size_t)b * p.Cout + 16 * i) * HW + p0);
+    }
+  };
+  auto store_staged = [&](float* buf) {
+    float* sY = buf;
+    float* sX = buf + T1_FLOATS;
+    const int base = (sc4 * 4) * YS + srow;
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      float* dy_ = sY + base + 16 * i;
+      dy_[0] = yr[i].x; dy_[YS] = yr[i].y; dy_[2 * YS] = yr[i].z; dy_[3 * YS] = yr[i].w;
+      const bool dead = (xdead >> i) & 1u;
+      float* dx_ = sX + base + 16 * i;
+      dx_[0] = dead ? 0.f : xr[i].x; dx_[YS] = dead ? 0.f : xr[i].y; dx_[2 * YS] = dead ? 0.f : xr[i].z; dx_[3 * YS] = dead ? 0.f : xr[i].w;
+    }
+  };
+
+  int t = split;
+  if (t < p.total_tiles) {
+    issue_loads(t);
+    store_staged(smem);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (; t < p.total_tiles; t += p.nsplit) {
+    const bool more = (t + p.nsplit < p.total_tiles);
+    if (more) issue_loads(t + p.nsplit);
+    const float* sY = smem + cur * 2 * T1_FLOATS;
+    const float* ya = sY + h * YS + wave * 32 + l31;                  // A: dY[pixel 2 kk + h][co]
+    const float* xb = sY + T1_FLOATS + h * YS + l31;                  // B: X[pixel 2 kk + h][ci group g]
+    int go[4] = {0, 32, 64, 96};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(go[g]));       // opaque bases: one ds_read_b32 + immediate per operand
+#pragma unroll
+    for (int kk = 0; kk < P1 / 2; ++kk) {
+      const float a = ya[2 * kk * YS];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[go[g] + 2 * kk * YS], acc[g], 0, 0, 0);
+    }
+    if (more) store_staged(smem + (cur ^ 1) * 2 * T1_FLOATS);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- this split's packed partial slab dwp[split][0][ci][co]
+  float* slab = p.dwp + (size_t)split * p.CinPad * p.CoutPad;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int ci = ci0 + g * 32 + l31;
+    if (ci < p.Cin) {
+      float* dst = slab + (size_t)ci * p.CoutPad + co0 + wave * 32 + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[g][4 * q + 0], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]);
+    }
+  }
+}
+
 }  // namespace
 
 namespace hdiff {
+
+bool wgrad1x1_applicable(const hdiff_conv_wgrad_desc* d) {
+  if (d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->in_stride != 1 || d->gn_scale != nullptr) return false;
+  if (d->out_sy != 1 || d->out_oy != 0 || d->out_sx != 1 || d->out_ox != 0) return false;
+  if (d->VH != d->H || d->VW != d->W || d->OH != d->H || d->OW != d->W) return false;
+  const long HW = (long)d->H * d->W;
+  const int Cin = d->C0 + d->C1;
+  if (HW % P1 != 0 || HW >= (1L << 30)) return false;
+  if (d->Cout % FM != 0 || Cin % 32 != 0 || d->CinPad != Cin || d->CoutPad != d->Cout) return false;
+  return true;
+}
+
+int wgrad1x1_nsplit(const hdiff_conv_wgrad_desc* d) {
+  const int base = (d->Cout / FM) * cdiv(d->C0 + d->C1, 128);
+  const long total = (long)d->B * ((long)d->H * d->W / P1);
+  long ns = 512 / base;                     // one workgroup per CU (132 KB of LDS): at most two full rounds of the 256 CUs
+  if (ns > total) ns = total;
+  return ns < 1 ? 1 : (int)ns;
+}
+
+int launch_wgrad1x1(const hdiff_conv_wgrad_desc* d, float* dwp, int nsplit, hipStream_t stream) {
+  Wgrad1 k{};
+  k.x0 = d->x0; k.x1 = d->x1; k.C0 = d->C0; k.C1 = d->C1; k.Cin = d->C0 + d->C1; k.dy = d->dy; k.Cout = d->Cout;
+  k.HW = d->H * d->W;
+  k.tiles_per_image = k.HW / P1;
+  k.total_tiles = d->B * k.tiles_per_image;
+  k.nsplit = nsplit; k.CinPad = d->CinPad; k.CoutPad = d->CoutPad; k.dwp = dwp;
+  HDIFF_CHECK_ARG(nsplit >= 1 && nsplit <= k.total_tiles, "conv2d_wgrad (1x1): nsplit %d not in [1, %d]", nsplit, k.total_tiles);
+  const size_t lds = (size_t)4 * T1_FLOATS * sizeof(float);
+  static uint64_t attr_mask = 0;
+  if (first_use_on_device(attr_mask))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  dim3 grid(d->Cout / FM, cdiv(k.Cin, 128), nsplit);
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(conv_wgrad1x1_kernel, grid, dim3(FT), lds, stream, k);
+  HDIFF_CHECK_LAUNCH("conv_wgrad1x1_kernel");
+  return HDIFF_OK;
+}
 
 bool wgrad3x3_applicable(const hdiff_conv_wgrad_desc* d) {
   if (d->ntaps != 9 || d->in_stride != 1) return false;

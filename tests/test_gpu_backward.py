@@ -46,6 +46,9 @@ def leaf(t, dev=None):
     (3, 3, 0, 32, 16, 16, 2, False, False, False),      # head conv
     (3, 32, 0, 3, 16, 16, 2, True, False, False),       # tail conv
     (3, 128, 0, 128, 32, 32, 2, True, True, True),
+    (1, 128, 0, 384, 16, 16, 2, False, False, False),   # in-projection shape: the 1x1 weight-gradient kernel (Cout % 128 == 0)
+    (1, 256, 128, 128, 8, 16, 2, False, False, True),   # concat shortcut 384 -> 128: three 128-channel chunks across the seam
+    (1, 96, 64, 256, 8, 8, 1, False, False, False),     # 160 input channels: a partial last chunk, seam inside a chunk
 ])
 def test_fused_conv_backward(k, C0, C1, cout, H, W, B, gn, vec, res):
     g = torch.Generator().manual_seed(k * 100 + C0 + cout)
