@@ -204,6 +204,19 @@ __global__ void linear_rows_bwd_w_kernel(const float* __restrict__ x, const int6
   if (k == 0 && db) db[n] = accumulate ? db[n] + sb : sb;
 }
 
+// g = sum_n dy[n] * W[n][k]: eight independent partial sums so that eight loads are in flight per lane (a single fma chain
+// waits one L2 round trip per term: 86 us for a 4 x 512 x 256 layer, 8 workgroups on the whole chip); fixed combination order.
+__device__ __forceinline__ float dot_rows(const float* __restrict__ dyb, const float* __restrict__ Wk, int N, int K) {
+  float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int n = 0;
+  for (; n + 8 <= N; n += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = fmaf(dyb[n + j], Wk[(size_t)(n + j) * K], g[j]);
+  }
+  for (; n < N; ++n) g[0] = fmaf(dyb[n], Wk[(size_t)n * K], g[0]);
+  return ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
+}
+
 __global__ void linear_rows_bwd_x_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int n_rows,
                                          const float* __restrict__ W, const float* __restrict__ dy, float* __restrict__ dx,
                                          int B, int K, int N, int swish_input, int pad_row) {
@@ -215,8 +228,7 @@ __global__ void linear_rows_bwd_x_kernel(const float* __restrict__ x, const int6
       int64_t row = idx[b];
       if (n_rows > 0) row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
       if (row == pad_row) continue;     // nn.Embedding(padding_idx): the padding row never receives a gradient
-      float g = 0.f;
-      for (int n = 0; n < N; ++n) g = fmaf(dy[(size_t)b * N + n], W[(size_t)n * K + k], g);
+      float g = dot_rows(dy + (size_t)b * N, W + k, N, K);
       if (swish_input) g *= dswishf(x[(size_t)row * K + k]);
       dx[(size_t)row * K + k] += g;
     }
@@ -225,8 +237,7 @@ __global__ void linear_rows_bwd_x_kernel(const float* __restrict__ x, const int6
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * K) return;
   const int b = i / K, k = i - b * K;
-  float g = 0.f;
-  for (int n = 0; n < N; ++n) g = fmaf(dy[(size_t)b * N + n], W[(size_t)n * K + k], g);
+  float g = dot_rows(dy + (size_t)b * N, W + k, N, K);
   if (swish_input) g *= dswishf(x[i]);
   dx[i] = g;
 }
