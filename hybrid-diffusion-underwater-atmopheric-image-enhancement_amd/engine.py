@@ -168,35 +168,41 @@ class Plan:
         self._keep.append(obj)
 
     def run(self, stream: Optional[int] = None) -> None:
-        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
-        for name, fn, args in self.ops:
-            rc = fn(*args, s)
-            if rc != 0:
-                _capi.check(rc, name)
+        # launches go to the plan's device whatever the caller's current device is (the C ABI launches on the current
+        # device; per-kernel attributes such as the dynamic-LDS limit are set per device on first use)
+        with torch.cuda.device(self.device):
+            s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+            for name, fn, args in self.ops:
+                rc = fn(*args, s)
+                if rc != 0:
+                    _capi.check(rc, name)
 
     def pack_weights(self, stream: Optional[int] = None) -> None:
-        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
-        for p in self.packs:
-            p.pack(s)
+        with torch.cuda.device(self.device):
+            s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+            for p in self.packs:
+                p.pack(s)
 
     # -- hipGraph -----------------------------------------------------------------------------------------------------
     def capture(self) -> None:
         """Capture the launch list into a hipGraph on a private stream (weights must already be packed)."""
         if self.graph.value:
             return
-        torch.cuda.synchronize(self.device)
-        self._graph_stream = torch.cuda.Stream(self.device)
-        s = self._graph_stream.cuda_stream
-        _capi.check(self.lib.hdiff_graph_begin(s), "graph_begin")
-        try:
-            self.run(s)
-        finally:
-            rc = self.lib.hdiff_graph_end(s, C.byref(self.graph))
-        _capi.check(rc, "graph_end")
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            self._graph_stream = torch.cuda.Stream(self.device)
+            s = self._graph_stream.cuda_stream
+            _capi.check(self.lib.hdiff_graph_begin(s), "graph_begin")
+            try:
+                self.run(s)
+            finally:
+                rc = self.lib.hdiff_graph_end(s, C.byref(self.graph))
+            _capi.check(rc, "graph_end")
 
     def replay(self, stream: Optional[int] = None) -> None:
-        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
-        _capi.check(self.lib.hdiff_graph_launch(self.graph, s), "graph_launch")
+        with torch.cuda.device(self.device):
+            s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+            _capi.check(self.lib.hdiff_graph_launch(self.graph, s), "graph_launch")
 
     def __del__(self):
         try:
