@@ -41,6 +41,13 @@ constexpr float RESCALE_LIMIT = 1.8446744e19f;   // 2^64: a row sum at or above 
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// one v_pk_add_f32 (pure: no memory, no side effects -- the compiler may schedule and CSE it like any VALU instruction)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <int D, int NQ>
 __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                     float* __restrict__ lse2, int C, int L, float qscale, int check) {
@@ -399,15 +406,22 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) Sq[ks] += negm4[qt];
       }
-      f32x2 sum2 = {0.f, 0.f};
+      // P as whole register quads, then the tile's row sums as PACKED adds on their halves: two v_pk_add_f32 per 16-key
+      // subtile, as inline asm because the compiler scalarises these vector adds (34 scalar + 19 packed adds per 64x64 scores
+      // in the element-wise form; every VALU instruction is issue time taken from the fp32 MFMA stream).
+      // gfx950 needs one wait state between a transcendental (v_exp_f32) and a VALU instruction reading its result, and the
+      // compiler's hazard recogniser does not look inside asm statements: all sixteen v_exp of the query tile are issued first
+      // and pinned above the adds, whose first reader of any v_exp result is then >= 1 instruction away
+      // (tests/test_host_cpu.py disassembles the library and checks exactly that).
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const f32x2 pa = {__builtin_amdgcn_exp2f(Sq[ks][0]), __builtin_amdgcn_exp2f(Sq[ks][1])};
-        const f32x2 pc = {__builtin_amdgcn_exp2f(Sq[ks][2]), __builtin_amdgcn_exp2f(Sq[ks][3])};
-        sum2 += pa;
-        sum2 += pc;
-        P[ks] = f32x4{pa.x, pa.y, pc.x, pc.y};
-      }
+      for (int ks = 0; ks < 4; ++ks)
+        P[ks] = f32x4{__builtin_amdgcn_exp2f(Sq[ks][0]), __builtin_amdgcn_exp2f(Sq[ks][1]), __builtin_amdgcn_exp2f(Sq[ks][2]),
+                      __builtin_amdgcn_exp2f(Sq[ks][3])};
+      __builtin_amdgcn_sched_barrier(0);
+      f32x2 sum2 = pk_add(__builtin_shufflevector(P[0], P[0], 0, 1), __builtin_shufflevector(P[0], P[0], 2, 3));
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks)
+        sum2 = pk_add(pk_add(sum2, __builtin_shufflevector(P[ks], P[ks], 0, 1)), __builtin_shufflevector(P[ks], P[ks], 2, 3));
       l_run[qt] += sum2;    // packed running sums (tile sums first: shorter rounding chains), folded after the last tile
     };
 #pragma unroll
