@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time plain launches instead of the hipGraph replay")
     ap.add_argument("--graph", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second, event-instrumented pass (no roofline)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="dev: run the N > 1 code path (rendezvous, barriers, max over ranks, aggregation) with every rank on "
+                         "cuda:0 over gloo -- RCCL refuses two ranks on one device; the numbers mean nothing")
     return ap.parse_args()
 
 
@@ -100,8 +103,13 @@ def main():
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if a.rehearse_one_gpu:
+            local = 0
+            torch.cuda.set_device(0)
+            td.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local)
+            td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if dist else 0)
@@ -214,7 +222,7 @@ def main():
                            "tests/test_gpu_ops.py::test_flash_attention_split_bf16_is_fp32_class)"}
 
     if dist:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device="cpu" if a.rehearse_one_gpu else dev, dtype=torch.float64)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -1,0 +1,80 @@
+"""Data-parallel training (BASELINE config C4's code path) with two ranks on the one GPU of the test box: replicated weights,
+per-rank batches, gradients accumulated by the HIP backward straight into FlatGradients' views, ONE reduce-scatter + all-gather
+per step, clip, AdamW.  The process group is gloo (RCCL refuses two ranks on one device); the collectives are the same calls
+the RCCL run makes (parallel._exchange_mean_).  Asserts: replicas stay bitwise identical over two steps, and the exchanged
+gradient is the mean of the two ranks' own gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import hdiff_amd  # noqa: F401
+    from hdiff_amd import parallel as P
+    from hdiff_amd.DiffusionFreeGuidence.DiffusionCondition import GaussianDiffusionTrainer
+    from hdiff_amd.DiffusionFreeGuidence.ModelCondition import UNet
+    P.init_from_env(backend="gloo")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(100 + rank)                                   # ranks start from DIFFERENT weights ...
+    net = UNet(T=8, num_labels=3, ch=32, ch_mult=[1, 2], num_res_blocks=1, dropout=0.0).to(dev).train()
+    P.broadcast_parameters_(net.parameters())                       # ... and are made replicas of rank 0
+    tr = GaussianDiffusionTrainer(net, 1e-4, 0.02, 8).to(dev)
+    weights = list(net.parameters())
+    opt = torch.optim.AdamW(weights, lr=1e-3, weight_decay=1e-4)
+    flat = P.FlatGradients(weights, world)
+    g = torch.Generator().manual_seed(7 + rank)                     # per-rank data
+    x0 = (torch.rand(2, 3, 16, 16, generator=g) * 2 - 1).to(dev)
+    labels = torch.tensor([1, 2 + rank], device=dev)
+    t = torch.tensor([3, 5 - rank], device=dev)
+    noise = torch.randn(2, 3, 16, 16, generator=g).to(dev)
+    checks = []
+    for step in range(2):
+        flat.zero_()
+        loss = tr(x0, labels, t=t, noise=noise).sum() / 2 ** 2.
+        loss.backward()
+        mine = flat.flat.clone()
+        sent = flat.exchange_mean_()
+        both = [torch.empty_like(mine.cpu()) for _ in range(world)]
+        dist.all_gather(both, mine.cpu())
+        want = (both[0] + both[1]) / 2
+        err = (flat.flat.cpu() - want).abs().max().item()
+        torch.nn.utils.clip_grad_norm_(weights, 1.0)
+        opt.step()
+        checks.append((err, want.abs().max().item(), sent))
+    digest = torch.cat([p.detach().reshape(-1) for p in weights]).cpu()
+    q.put((rank, checks, digest.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_train_identical_replicas_on_one_gpu():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, c0, w0), (_, c1, w1) = res
+    for (err, mag, sent) in c0 + c1:
+        assert err <= 1e-6 * mag + 1e-12, (err, mag)       # exchanged gradient = mean of the ranks' own gradients
+        assert sent >= 4 * 800_000                            # the whole flat buffer (0.88 M parameters) went through the collective
+    assert (w0 == w1).all(), "replicas diverged"

@@ -20,8 +20,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=256); ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--dropout", type=float, default=0.15)
+ap.add_argument("--rehearse-one-gpu", action="store_true",
+                help="dev: the data-parallel code path with every rank on cuda:0 over gloo (RCCL refuses two ranks on one device)")
 a = ap.parse_args()
-rank, local, world = parallel.init_from_env()
+rank, local, world = parallel.init_from_env(backend="gloo" if a.rehearse_one_gpu else None)
+if a.rehearse_one_gpu:
+    local = 0
 dev = torch.device("cuda", local if world > 1 else 0)
 torch.cuda.set_device(dev)
 torch.manual_seed(0)                                     # identical replicas
@@ -52,7 +56,7 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps): l = step()
 torch.cuda.synchronize()
 if world > 1: torch.distributed.barrier()
-dt = parallel.max_over_ranks((time.perf_counter() - t0) / a.steps, dev)
+dt = parallel.max_over_ranks((time.perf_counter() - t0) / a.steps, None if a.rehearse_one_gpu else dev)
 fwd = {64: 74.0, 128: 529.6, 256: 5857.4}[a.size]
 if rank == 0:
     print(json.dumps({"size": a.size, "batch_per_gpu": a.batch, "n_gpus": world, "s_per_step": dt,
