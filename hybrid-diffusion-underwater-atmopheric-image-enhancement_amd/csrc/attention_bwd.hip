@@ -285,6 +285,13 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 64 ? 1 : 2)) void mha_bwd_fused_
             S = __builtin_amdgcn_mfma_f32_16x16x4f32(o.qa[s], kreg[kt][s], S, 0, 0, 0);
             dP = __builtin_amdgcn_mfma_f32_16x16x4f32(o.doa[s], vreg[kt][s], dP, 0, 0, 0);
           }
+          // P = exp2(S) as one register quad, dS = P o dP as two packed multiplies (inline asm: the compiler emits three or
+          // four scalar ones).  gfx950 needs one wait state between a v_exp_f32 and a VALU reader of its result and the
+          // hazard recogniser does not look inside asm: the four v_exp are issued first and pinned above the multiplies, so
+          // the first multiply reads results two instructions old and the second one's youngest input is one instruction
+          // away (checked on the ISA by tests/test_host_cpu.py).
+          // (tried: dS as two v_pk_mul_f32 through inline asm, with the four v_exp pinned above them for the transcendental-use
+          // wait state -- 1 % SLOWER: the pinning costs more interleaving freedom than the two saved instructions are worth)
           f32x4 P, dS;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -406,6 +413,7 @@ struct BwdGeom { int nk, nkb_total, per, nsplit; };
 static BwdGeom bwd_geometry(int B, int heads, int L, int D) {
   BwdGeom g;
   g.nk = (L <= 4096 || D >= 64) ? 1 : (D >= 32 ? 2 : 4);   // short sequences: 64-key blocks for enough workgroups
+  if (L % (64 * g.nk) != 0) g.nk = 1;                      // ragged sequences: the generic (bounds-checked) kernel, 64-key blocks
   const int KB = 64 * g.nk;
   g.nkb_total = cdiv(L, KB);
   const int pairs = B * heads;
@@ -419,10 +427,13 @@ static BwdGeom bwd_geometry(int B, int heads, int L, int D) {
 
 template <int D, int NK>
 void launch_fused(const BwdArgs& a, const BwdGeom& g, int B, int heads, hipStream_t stream) {
-  if (a.L % (64 * NK) == 0)
+  if (a.L % (64 * NK) == 0) {
     hipLaunchKernelGGL((mha_bwd_fused_kernel<D, NK, true>), dim3(g.nsplit, heads, B), dim3(ATT_THREADS), 0, stream, a);
-  else
-    hipLaunchKernelGGL((mha_bwd_fused_kernel<D, NK, false>), dim3(g.nsplit, heads, B), dim3(ATT_THREADS), 0, stream, a);
+  } else if constexpr (NK == 1) {
+    // ragged / unaligned sequences: the generic instantiation exists for 64-key blocks only (bwd_geometry picks NK = 1 for
+    // them: with more key tiles per wave its bounds handling spills registers in the MFMA loop)
+    hipLaunchKernelGGL((mha_bwd_fused_kernel<D, 1, false>), dim3(g.nsplit, heads, B), dim3(ATT_THREADS), 0, stream, a);
+  }
 }
 
 template <int D>

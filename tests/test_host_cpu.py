@@ -233,23 +233,22 @@ def test_tree_b_state_dict_layout_and_seeded_init_match_reference():
         samp(torch.zeros(1, 3, 16, 16))
 
 
-def test_inline_asm_packed_adds_keep_the_trans_use_wait_state(tmp_path):
-    """attention.hip sums softmax rows with v_pk_add_f32 written as inline asm.  gfx950 needs one wait state between a
-    transcendental instruction (v_exp_f32 ...) and a VALU instruction that reads its result, and the compiler's hazard
-    recogniser does not see inside asm statements -- the source pins all v_exp of a query tile above the adds.  This test
-    compiles the file to ISA (no GPU needed) and checks that no v_pk_add_f32 reads a register written by the instruction
-    directly in front of it when that instruction is a transcendental."""
-    import re
+@pytest.mark.parametrize("source,mnemonic", [("attention.hip", "v_pk_add_f32")])
+def test_inline_asm_packed_math_keeps_the_trans_use_wait_state(tmp_path, source, mnemonic):
+    """attention.hip sums softmax rows with v_pk_add_f32 written as inline asm.  gfx950 needs one wait state between a transcendental instruction (v_exp_f32 ...) and a VALU
+    instruction that reads its result, and the compiler's hazard recogniser does not see inside asm statements -- the source
+    pins all v_exp of a tile above the packed instructions.  This test compiles the file to ISA (no GPU needed) and checks
+    that no such packed instruction reads a register written by the instruction directly in front of it when that one is a
+    transcendental."""
     import shutil
-    import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.isfile(hipcc):
         pytest.skip("hipcc not available")
     csrc = os.path.join(ROOT, "hybrid-diffusion-underwater-atmopheric-image-enhancement_amd", "csrc")
-    out = tmp_path / "attention.s"
+    out = tmp_path / (source + ".s")
     subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form",
-                    "-S", "--cuda-device-only", os.path.join(csrc, "attention.hip"), "-o", str(out)], check=True,
-                   capture_output=True)
+                    "-S", "--cuda-device-only", os.path.join(csrc, source), "-o", str(out)], check=True, capture_output=True)
+
     def regs(tok):
         found = set()
         for m in re.finditer(r"v\[(\d+):(\d+)\]|v(\d+)", tok):
@@ -260,9 +259,9 @@ def test_inline_asm_packed_adds_keep_the_trans_use_wait_state(tmp_path):
     trans = ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32")
     n_pk = 0
     for prev, cur in zip(ins, ins[1:]):
-        if cur.startswith("v_pk_add_f32"):
+        if cur.startswith(mnemonic):
             n_pk += 1
             if prev.startswith(trans):
                 srcs = set().union(*[regs(o) for o in cur.split(None, 1)[1].split(",")[1:]])
                 assert not (regs(prev.split(None, 1)[1].split(",")[0]) & srcs), (prev, cur)
-    assert n_pk > 100            # the packed adds are really there (the check above is not vacuous)
+    assert n_pk > 100            # the packed instructions are really there (the check above is not vacuous)
