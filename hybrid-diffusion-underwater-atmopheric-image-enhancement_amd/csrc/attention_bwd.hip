@@ -101,6 +101,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 64 ? 1 : 2)) void mha_bwd_fused_
   constexpr int NLD = (NV4 + ATT_THREADS - 1) / ATT_THREADS;
   constexpr bool OLD_EARLY = (MT == 1);
   constexpr bool OPS_AHEAD = (MT == 1);           // operands of the next query subtile fetched during the current one
+  constexpr bool PIPELINED = (MT == 1) && FAST && (NK >= 2);   // (d_head 32: 47 spilled registers with the second S / dP pair)   // chains of the next pair issued ahead of this pair's VALU step
   constexpr bool KT_FENCE = (MT > 1);             // d_head 32: keep the key tiles' MFMA groups apart (register budget, see do_tile)
 
   __shared__ __attribute__((aligned(16))) float sQ[2][DP * KROW];
@@ -255,80 +256,122 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 64 ? 1 : 2)) void mha_bwd_fused_
       o.nd = f32x4{d4.x, d4.y, d4.z, d4.w};
     };
 
-    // One staged query tile.  MASK: the key block holds keys >= L (their P must not reach dQ even as 0 * inf).
-    auto do_tile = [&](auto mask_tag, int buf, int dqbuf) {
+    // The MFMA work of one (query subtile, key tile) pair: the two 16x16 chains S / dP, the VALU step P = exp2(S),
+    // dS = P o dP, the transposition of dS through the wave's scratch, and the three accumulating products.
+    auto chains = [&](const QOps& o, int kt, f32x4& S, f32x4& dP) {
+      S = o.nl;
+      dP = o.nd;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        S = __builtin_amdgcn_mfma_f32_16x16x4f32(o.qa[s], kreg[kt][s], S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_16x16x4f32(o.doa[s], vreg[kt][s], dP, 0, 0, 0);
+      }
+    };
+    // (tried: dS as two v_pk_mul_f32 through inline asm, with the four v_exp pinned above them for the transcendental-use
+    // wait state -- 1 % SLOWER: the pinning costs more interleaving freedom than the two saved instructions are worth)
+    auto softmax_grad = [&](auto mask_tag, int kt, const f32x4& S, const f32x4& dP, f32x4& P, f32x4& dS, f32x4& tr) {
       constexpr bool MASK = decltype(mask_tag)::value;
-      QOps ops[2];
-      if (OPS_AHEAD) load_ops(ops[0], buf, 0);
 #pragma unroll
-      for (int qs = 0; qs < 4; ++qs) {
-        // The scheduler must not hoist operand loads across subtiles on its own (it then holds the operands of all four
-        // live at once: 96 extra registers, one wave per SIMD).  d_head <= 16 has the registers to fetch ONE subtile ahead
-        // by hand, so that no subtile starts with an LDS round trip; d_head 32 loads them in place.
-        __builtin_amdgcn_sched_barrier(0);
-        if (OPS_AHEAD) {
-          if (qs + 1 < 4) load_ops(ops[(qs + 1) & 1], buf, qs + 1);
-        } else {
-          load_ops(ops[qs & 1], buf, qs);
+      for (int r = 0; r < 4; ++r) {
+        float p = __builtin_amdgcn_exp2f(S[r]);
+        if (MASK && !kvalid[kt]) p = 0.f;
+        P[r] = p;
+        dS[r] = p * dP[r];
+      }
+      // transpose dS through the wave's scratch: [key = lane column][query 4g..4g+3] -> rows of keys for the reader
+      asm volatile("" ::: "memory");
+      *reinterpret_cast<f32x4*>(&sT[wave][i16 * TS + 4 * g]) = dS;
+      asm volatile("" ::: "memory");      // DS operations of one wave execute in order: no wait between write and read
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tr[r] = sT[wave][(4 * g + r) * TS + i16];
+      asm volatile("" ::: "memory");
+    };
+    auto accumulate = [&](const QOps& o, int kt, const f32x4& P, const f32x4& dS, const f32x4& tr, f32x4 (&dQa)[MT]) {
+      // dV / dK first (they only need P / dS), dQ behind them: its operand is the LDS read-back, covered by the MFMAs in
+      // front, and its accumulation chain is spread out instead of four dependent MFMAs back to back
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          dV[mt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.dov[mt][r], P[r], dV[mt][kt], 0, 0, 0);
+          dK[mt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.qv[mt][r], dS[r], dK[mt][kt], 0, 0, 0);
+          if (r >= 2) dQa[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ktr[kt][mt][r - 2], tr[r - 2], dQa[mt], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        const QOps& o = ops[qs & 1];
-        f32x4 dQa[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) dQa[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < NK; ++kt) {
-          if (KT_FENCE) __builtin_amdgcn_sched_barrier(0);
-          f32x4 S = o.nl, dP = o.nd;
-#pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            S = __builtin_amdgcn_mfma_f32_16x16x4f32(o.qa[s], kreg[kt][s], S, 0, 0, 0);
-            dP = __builtin_amdgcn_mfma_f32_16x16x4f32(o.doa[s], vreg[kt][s], dP, 0, 0, 0);
-          }
-          // P = exp2(S) as one register quad, dS = P o dP as two packed multiplies (inline asm: the compiler emits three or
-          // four scalar ones).  gfx950 needs one wait state between a v_exp_f32 and a VALU reader of its result and the
-          // hazard recogniser does not look inside asm: the four v_exp are issued first and pinned above the multiplies, so
-          // the first multiply reads results two instructions old and the second one's youngest input is one instruction
-          // away (checked on the ISA by tests/test_host_cpu.py).
-          // (tried: dS as two v_pk_mul_f32 through inline asm, with the four v_exp pinned above them for the transcendental-use
-          // wait state -- 1 % SLOWER: the pinning costs more interleaving freedom than the two saved instructions are worth)
-          f32x4 P, dS;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float p = __builtin_amdgcn_exp2f(S[r]);
-            if (MASK && !kvalid[kt]) p = 0.f;
-            P[r] = p;
-            dS[r] = p * dP[r];
-          }
-          // transpose dS through the wave's scratch: [key = lane column][query 4g..4g+3] -> rows of keys for the reader
-          asm volatile("" ::: "memory");
-          *reinterpret_cast<f32x4*>(&sT[wave][i16 * TS + 4 * g]) = dS;
-          asm volatile("" ::: "memory");      // DS operations of one wave execute in order: no wait between write and read
-          f32x4 tr;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tr[r] = sT[wave][(4 * g + r) * TS + i16];
-          asm volatile("" ::: "memory");
-          // pin the read-back HERE, in front of the eight dV / dK MFMAs that cover its latency (the scheduler otherwise sinks
-          // it next to its first use and the wave waits a full LDS round trip per tile)
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              dV[mt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.dov[mt][r], P[r], dV[mt][kt], 0, 0, 0);
-              dK[mt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.qv[mt][r], dS[r], dK[mt][kt], 0, 0, 0);
-            }
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-              dQa[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ktr[kt][mt][r], tr[r], dQa[mt], 0, 0, 0);
-        }
-        // dQ^T tile of this wave: lane = query, registers = channels 4g..4g+3
+      for (int r = 2; r < 4; ++r)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
+          dQa[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ktr[kt][mt][r], tr[r], dQa[mt], 0, 0, 0);
+    };
+    auto store_dq = [&](int dqbuf, int qs, const f32x4 (&dQa)[MT]) {
+      // dQ^T tile of this wave: lane = query, registers = channels 4g..4g+3
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sDQ[dqbuf][wave][(mt * 16 + 4 * g + r) * DQS + qs * 16 + i16] = dQa[mt][r];
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sDQ[dqbuf][wave][(mt * 16 + 4 * g + r) * DQS + qs * 16 + i16] = dQa[mt][r];
+    };
+
+    // One staged query tile.  MASK: the key block holds keys >= L (their P must not reach dQ even as 0 * inf).
+    auto do_tile = [&](auto mask_tag, int buf, int dqbuf) {
+      QOps ops[2];
+      if constexpr (PIPELINED) {
+        // Software pipeline over the 4 * NK (subtile, key tile) pairs: the S / dP chains of pair i+1 are ISSUED before the
+        // VALU step of pair i, so that step never waits for an MFMA result (its chains were issued a whole pair earlier) and
+        // the matrix pipe has the next chains queued while the wave does its exp / multiply / LDS transposition.  Operands of
+        // subtile qs+1 are fetched from LDS at the first pair of subtile qs.  Scheduling barriers pin the stage order.
+        constexpr int NPAIR = 4 * NK;
+        f32x4 S[2], dP[2], dQa[MT];
+        load_ops(ops[0], buf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        chains(ops[0], 0, S[0], dP[0]);
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) {
+          const int qs = i / NK, kt = i - qs * NK;
+          if (kt == 0) {
+            if (qs + 1 < 4) load_ops(ops[(qs + 1) & 1], buf, qs + 1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) dQa[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 1 < NPAIR) chains(ops[((i + 1) / NK) & 1], (i + 1) % NK, S[(i + 1) & 1], dP[(i + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 P, dS, tr;
+          softmax_grad(mask_tag, kt, S[i & 1], dP[i & 1], P, dS, tr);
+          __builtin_amdgcn_sched_barrier(0);
+          accumulate(ops[qs & 1], kt, P, dS, tr, dQa);
+          if (kt == NK - 1) store_dq(dqbuf, qs, dQa);
+        }
+      } else {
+        if (OPS_AHEAD) load_ops(ops[0], buf, 0);
+#pragma unroll
+        for (int qs = 0; qs < 4; ++qs) {
+          // The scheduler must not hoist operand loads across subtiles on its own (it then holds the operands of all four
+          // live at once: 96 extra registers, one wave per SIMD).  d_head <= 16 has the registers to fetch ONE subtile ahead
+          // by hand, so that no subtile starts with an LDS round trip; d_head 32 loads them in place.
+          __builtin_amdgcn_sched_barrier(0);
+          if (OPS_AHEAD) {
+            if (qs + 1 < 4) load_ops(ops[(qs + 1) & 1], buf, qs + 1);
+          } else {
+            load_ops(ops[qs & 1], buf, qs);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const QOps& o = ops[qs & 1];
+          f32x4 dQa[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) dQa[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < NK; ++kt) {
+            if (KT_FENCE) __builtin_amdgcn_sched_barrier(0);
+            f32x4 S, dP, P, dS, tr;
+            chains(o, kt, S, dP);
+            softmax_grad(mask_tag, kt, S, dP, P, dS, tr);
+            // pin the read-back HERE, in front of the dV / dK MFMAs that cover its latency (the scheduler otherwise sinks it
+            // next to its first use and the wave waits a full LDS round trip per pair)
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(o, kt, P, dS, tr, dQa);
+          }
+          store_dq(dqbuf, qs, dQa);
+        }
       }
     };
 
