@@ -104,7 +104,7 @@ def train(modelConfig: Dict) -> List[float]:
     parallel.broadcast_parameters_(net.parameters())
     weights = list(net.parameters())
     opt = torch.optim.AdamW(weights, lr=cfg["lr"], weight_decay=WEIGHT_DECAY)
-    flat_grads = parallel.FlatGradients(weights, world) if world > 1 else None     # gradients as views of one exchange buffer
+    flat_grads = parallel.FlatGradients(weights, world, overlap=True) if world > 1 else None   # views of one exchange buffer; bucket reduce-scatters start during backward
     schedule = GradualWarmupScheduler(
         optimizer=opt, multiplier=cfg["multiplier"], warm_epoch=cfg["epoch"] // 10,
         after_scheduler=torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=opt, T_max=cfg["epoch"], eta_min=0, last_epoch=-1))

@@ -8,7 +8,8 @@ DDP with one process per GPU (utils/rotinas.py:572-577, 619).  The hot path shar
 * training: replicated weights, per-rank mini-batch, ONE exchange per optimizer step: the mean of the 47.8 M fp32
   gradients (190.8 MB).  On the MI355X node xGMI is a full mesh of point-to-point links, so the flat gradient buffer is
   reduced with reduce-scatter + all-gather (every link busy at once) rather than a ring all-reduce of small buckets.
-  The gradients live as views in that flat buffer (FlatGradients): no gather / scatter copies around the exchange.
+  The gradients live as views in that flat buffer (FlatGradients): no gather / scatter copies around the exchange, and
+  the reduce-scatter of each 64 MB bucket starts from a gradient hook while backward is still running.
   NO scaling curve has been measured yet (the build box has one GPU; the driver's 8-GPU run was skipped in round 1).
 """
 from __future__ import annotations
@@ -81,39 +82,114 @@ class FlatGradients:
         flat = FlatGradients(params)         # once
         flat.zero_()                         # instead of optimizer.zero_grad(): zero the buffer, (re)attach p.grad
         loss.backward(); flat.exchange_mean_(); clip_grad_norm_(params, ...); optimizer.step()
+
+    The buffer holds the parameters in REVERSE order (backward produces the last layer's gradients first) and is cut into
+    buckets of about `bucket_bytes` (each padded to a multiple of the world size).  With `overlap=True` every parameter
+    carries a post-accumulate hook; when the last gradient of a bucket has landed -- and every earlier bucket has been
+    started, so all ranks issue the collectives in one order -- the bucket's reduce-scatter is started asynchronously while
+    backward goes on.  `exchange_mean_()` starts whatever has not been started (parameters without a gradient), waits,
+    scales the shards and all-gathers them back into the views.  64 MB buckets: large enough that the full-mesh xGMI
+    reduce-scatter runs at link rate, small enough that only the first layers' bucket is left when backward ends.
     """
 
-    def __init__(self, params: Sequence[torch.nn.Parameter], world: int | None = None):
+    def __init__(self, params: Sequence[torch.nn.Parameter], world: int | None = None, overlap: bool = False,
+                 bucket_bytes: int = 64 << 20):
         self.params = [p for p in params if p.requires_grad]
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-        n = sum(p.numel() for p in self.params)
-        self.numel = n
-        padded = (n + self.world - 1) // self.world * self.world
+        w = self.world
         dev = self.params[0].device if self.params else "cpu"
-        self.flat = torch.zeros(padded, dtype=torch.float32, device=dev)
-        self.views: List[torch.Tensor] = []
-        off = 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+        order = list(range(len(self.params)))[::-1]
+        # bucket boundaries over the reversed parameter list
+        self.buckets: List[Tuple[int, int]] = []           # [lo, hi) in the flat buffer, hi - lo divisible by world
+        owner = [0] * len(self.params)
+        offs = [0] * len(self.params)
+        off, lo, cap = 0, 0, max(int(bucket_bytes) // 4, 1)
+        for i in order:
+            p = self.params[i]
+            if off > lo and off - lo + p.numel() > cap:     # close the bucket before this parameter
+                off = lo + (off - lo + w - 1) // w * w
+                self.buckets.append((lo, off))
+                lo = off
+            owner[i], offs[i] = len(self.buckets), off
             off += p.numel()
+        off = lo + (off - lo + w - 1) // w * w
+        if off > lo or not self.buckets:
+            self.buckets.append((lo, off))
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.views: List[torch.Tensor] = [self.flat[offs[i]:offs[i] + p.numel()].view_as(p) for i, p in enumerate(self.params)]
+        self.shards = [torch.empty((hi - lo) // w, dtype=torch.float32, device=dev) for lo, hi in self.buckets]
+        self._owner = owner
+        self._count = [0] * len(self.buckets)
+        for b in owner:
+            self._count[b] += 1
+        self.overlap = bool(overlap) and w > 1
+        self._pending: List[int] = []
+        self._ready: List[bool] = []
+        self._work: list = []
+        self._next = 0
+        self._hooks = []
+        if self.overlap:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self._arm()
+
+    def _arm(self) -> None:
+        self._pending = list(self._count)
+        self._ready = [False] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._next = 0
+
+    def _make_hook(self, i: int):
+        def hook(p: torch.Tensor) -> None:
+            if p.grad is None or p.grad.data_ptr() != self.views[i].data_ptr():     # the view was replaced behind our back: exchange_mean_ repairs and starts it
+                return
+            b = self._owner[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._ready[b] = True
+                self._start_ready()
+        return hook
+
+    def _start(self, b: int) -> None:
+        lo, hi = self.buckets[b]
+        self._work[b] = dist.reduce_scatter_tensor(self.shards[b], self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _start_ready(self) -> None:
+        while self._next < len(self.buckets) and self._ready[self._next]:
+            self._start(self._next)
+            self._next += 1
 
     def zero_(self) -> None:
         self.flat.zero_()
         for p, v in zip(self.params, self.views):
             p.grad = v                      # parameters that receive no gradient this step contribute zeros
+        self._arm()
 
     def exchange_mean_(self) -> int:
         """Returns the bytes each rank contributes to the exchange (0 when there is nothing to exchange)."""
         if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
             return 0
-        for p, v in zip(self.params, self.views):
-            if p.grad is not v:             # someone replaced the view (e.g. optimizer.zero_grad(set_to_none=True))
+        started = self._next
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():     # someone replaced the view (e.g. zero_grad(set_to_none=True))
+                assert self._owner[i] >= started, "a gradient view was replaced after its bucket had been sent"
                 if p.grad is None:
                     v.zero_()
                 else:
                     v.copy_(p.grad)
                 p.grad = v
-        _exchange_mean_(self.flat, self.world)
+        for b in range(self._next, len(self.buckets)):      # buckets the hooks did not start (or all of them, overlap off)
+            self._start(b)
+        self._next = len(self.buckets)
+        gathers = []
+        for b, (lo, hi) in enumerate(self.buckets):
+            self._work[b].wait()
+            self.shards[b].div_(self.world)
+            gathers.append(dist.all_gather_into_tensor(self.flat[lo:hi], self.shards[b], async_op=True))
+        for g in gathers:
+            g.wait()
+        self._arm()
         return self.flat.numel() * 4
 
 

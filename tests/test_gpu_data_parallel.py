@@ -37,7 +37,8 @@ def _worker(rank, world, port, q):
     tr = GaussianDiffusionTrainer(net, 1e-4, 0.02, 8).to(dev)
     weights = list(net.parameters())
     opt = torch.optim.AdamW(weights, lr=1e-3, weight_decay=1e-4)
-    flat = P.FlatGradients(weights, world)
+    flat = P.FlatGradients(weights, world, overlap=True, bucket_bytes=1 << 20)      # ~4 buckets, sent from the gradient hooks
+    assert len(flat.buckets) >= 3
     g = torch.Generator().manual_seed(7 + rank)                     # per-rank data
     x0 = (torch.rand(2, 3, 16, 16, generator=g) * 2 - 1).to(dev)
     labels = torch.tensor([1, 2 + rank], device=dev)
@@ -48,7 +49,8 @@ def _worker(rank, world, port, q):
         flat.zero_()
         loss = tr(x0, labels, t=t, noise=noise).sum() / 2 ** 2.
         loss.backward()
-        mine = flat.flat.clone()
+        assert flat._next >= 1, "no bucket left during backward"
+        mine = flat.flat.clone()                                     # (the reduce-scatter writes the shards, not the buffer)
         sent = flat.exchange_mean_()
         both = [torch.empty_like(mine.cpu()) for _ in range(world)]
         dist.all_gather(both, mine.cpu())

@@ -69,6 +69,21 @@ def _worker(rank, world, port, q):
         assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(fg.params, fg.views)), "autograd replaced a view"
         sent = fg.exchange_mean_()
         flat_results.append((mine, [p.grad.clone() for p in ps], sent))
+    # the overlapped form the training loop uses: tiny buckets (several per model), reduce-scatters started from the
+    # gradient hooks during backward, in bucket order; step 1 replaces one view with None (zero_grad(set_to_none) style)
+    # (buckets are sent in order, so a parameter that never gets a gradient holds back its bucket and the later ones until
+    # exchange_mean_: it is placed first here = in the last bucket)
+    fo = P.FlatGradients([unused] + list(net.parameters()), overlap=True, bucket_bytes=64)
+    assert fo.overlap and len(fo.buckets) >= 3 and all((hi - lo) % world == 0 for lo, hi in fo.buckets)
+    started_in_backward = []
+    for step in range(2):
+        fo.zero_()
+        xb = torch.randn(4, 6, generator=torch.Generator().manual_seed(10 * step + rank))
+        net(xb).pow(2).sum().backward()
+        started_in_backward.append(fo._next)
+        sent = fo.exchange_mean_()
+        flat_results.append((flat_results[step][0], [p.grad.clone() for p in ps], sent))
+    flat_results.append(started_in_backward)
     lo, hi = P.shard_range(11, world, rank)
     t = P.max_over_ranks(1.0 + rank)
     q.put(_plain((rank, w0, local, [p.grad.clone() for p in params], nbytes, (lo, hi), t, P.rank_seed(5, rank), flat_results)))
@@ -96,6 +111,9 @@ def test_two_rank_gradient_exchange_and_sharding():
     assert s0 == (0, 6) and s1 == (6, 11)                              # contiguous, balanced, exhaustive
     assert t0 == t1 == 2.0                                             # max over ranks
     assert seed0 != seed1
+    started0, started1 = fr0.pop(), fr1.pop()
+    assert started0 == started1 and min(started0) >= 1                 # buckets left the hooks during backward, same on both ranks
+    assert len(fr0) == 4
     for (mine0, avg0, sent0), (mine1, avg1, sent1) in zip(fr0, fr1):
         assert sent0 == sent1 and sent0 >= (6 * 5 + 5 + 5 * 2 + 2 + 3) * 4
         for a, b, m0, m1 in zip(avg0, avg1, mine0, mine1):

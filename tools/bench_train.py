@@ -34,7 +34,7 @@ parallel.broadcast_parameters_(m.parameters())
 tr = GaussianDiffusionTrainer(m, 1e-4, 0.02, 1000).to(dev)
 weights = list(m.parameters())
 opt = torch.optim.AdamW(weights, lr=1e-4, weight_decay=1e-4)
-flat = parallel.FlatGradients(weights, world) if world > 1 else None
+flat = parallel.FlatGradients(weights, world, overlap=True) if world > 1 else None
 g = torch.Generator().manual_seed(1 + rank)              # per-rank data
 x0 = (torch.rand(a.batch, 3, a.size, a.size, generator=g) * 2 - 1).to(dev)
 labels = (torch.arange(a.batch) % 2 + 1).to(dev)
