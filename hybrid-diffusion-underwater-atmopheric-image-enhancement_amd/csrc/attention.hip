@@ -506,9 +506,9 @@ template <int D>
 int launch_d(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, hipStream_t stream) {
   const float qscale = 1.4426950408889634f / sqrtf((float)D);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  if constexpr (D >= 64) {
-    // d_head 64 (ch_mult containing 4 at ch = 128: C = 512): the running-max kernel with one query tile per wave -- the
-    // register budget of the wider tiles does not stretch to 16 k-steps; not a shape of the default model
+  if constexpr (D >= 48) {
+    // d_head 48 / 64 (ch_mult containing 3 or 4 at ch = 128: C = 384 / 512): the running-max kernel with one query tile per
+    // wave -- the register budget of the wider tiles does not stretch to 12-16 k-steps; not shapes of the default model
     launch_v<D, 1>(qkv, o, lse2, B, C, heads, L, qscale, 0, stream);
   } else {
     int nq = (L >= 512) ? 4 : 1;   // 4 query tiles per wave: 3 waves per SIMD at d_head 16, 2 at d_head 32 (8 tiles measured no faster)
@@ -543,11 +543,14 @@ extern "C" int hdiff_mha_flash_fwd(const float* qkv, float* o, float* lse2, int 
   switch (D) {
     case 4: return launch_d<4>(qkv, o, lse2, B, C, heads, L, s);
     case 8: return launch_d<8>(qkv, o, lse2, B, C, heads, L, s);
+    case 12: return launch_d<12>(qkv, o, lse2, B, C, heads, L, s);
     case 16: return launch_d<16>(qkv, o, lse2, B, C, heads, L, s);
+    case 24: return launch_d<24>(qkv, o, lse2, B, C, heads, L, s);
     case 32: return launch_d<32>(qkv, o, lse2, B, C, heads, L, s);
+    case 48: return launch_d<48>(qkv, o, lse2, B, C, heads, L, s);
     case 64: return launch_d<64>(qkv, o, lse2, B, C, heads, L, s);
     default: break;
   }
-  hdiff::set_error("mha_flash_fwd: head dim %d not in {4, 8, 16, 32, 64}", D);
+  hdiff::set_error("mha_flash_fwd: head dim %d not in {4, 8, 12, 16, 24, 32, 48, 64}", D);
   return HDIFF_ERR_INVALID;
 }

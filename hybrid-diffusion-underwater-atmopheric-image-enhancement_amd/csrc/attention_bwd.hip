@@ -90,7 +90,7 @@ struct BwdArgs {
 // FAST: L is a multiple of the key block (hence of the 64-query tile and of 4): no bounds checks, no masks, no branches in
 // the staging code.  The generic instantiation handles ragged / unaligned sequences.
 template <int D, int NK, bool FAST>
-__global__ __launch_bounds__(ATT_THREADS, (D >= 64 ? 1 : 2)) void mha_bwd_fused_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(ATT_THREADS, (D >= 48 ? 1 : 2)) void mha_bwd_fused_kernel(const BwdArgs a) {
   constexpr int KS = D / 4;                       // k-steps of the S / dP products
   constexpr int MT = (D + 15) / 16;               // 16-row M tiles of the accumulating products
   constexpr int DP = MT * 16;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 64 ? 1 : 2)) void mha_bwd_fused_
   constexpr int NLD = (NV4 + ATT_THREADS - 1) / ATT_THREADS;
   constexpr bool OLD_EARLY = (MT == 1);
   constexpr bool OPS_AHEAD = (MT == 1);           // operands of the next query subtile fetched during the current one
-  constexpr bool PIPELINED = (MT == 1) && FAST && (NK >= 2);   // (d_head 32: 47 spilled registers with the second S / dP pair)   // chains of the next pair issued ahead of this pair's VALU step
+  constexpr bool PIPELINED = (MT == 1) && FAST && (NK >= 2);   // chains of the next pair issued ahead of this pair's VALU step (d_head 32: 47 spilled registers with the second S / dP pair)
   constexpr bool KT_FENCE = (MT > 1);             // d_head 32: keep the key tiles' MFMA groups apart (register budget, see do_tile)
 
   __shared__ __attribute__((aligned(16))) float sQ[2][DP * KROW];
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 64 ? 1 : 2)) void mha_bwd_fused_
 struct BwdGeom { int nk, nkb_total, per, nsplit; };
 static BwdGeom bwd_geometry(int B, int heads, int L, int D) {
   BwdGeom g;
-  g.nk = (L <= 4096 || D >= 64) ? 1 : (D >= 32 ? 2 : 4);   // short sequences: 64-key blocks for enough workgroups
+  g.nk = (L <= 4096 || D >= 48) ? 1 : (D > 16 ? 2 : 4);   // short sequences: 64-key blocks for enough workgroups
   if (L % (64 * g.nk) != 0) g.nk = 1;                      // ragged sequences: the generic (bounds-checked) kernel, 64-key blocks
   const int KB = 64 * g.nk;
   g.nkb_total = cdiv(L, KB);
@@ -498,12 +498,12 @@ int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* 
   const int total = B * heads * L;
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   hipLaunchKernelGGL(mha_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, o, d_o, delta, C, D, L, total);
-  if constexpr (D >= 64) {
-    launch_fused<D, 1>(a, g, B, heads, stream);             // d_head 64: 16 keys per wave is what the registers hold
+  if constexpr (D >= 48) {
+    launch_fused<D, 1>(a, g, B, heads, stream);             // d_head 48 / 64: 16 keys per wave is what the registers hold
   } else {
     if (g.nk == 1) launch_fused<D, 1>(a, g, B, heads, stream);
     else if (g.nk == 2) launch_fused<D, 2>(a, g, B, heads, stream);
-    else launch_fused<D, (D >= 32 ? 2 : 4)>(a, g, B, heads, stream);
+    else launch_fused<D, (D > 16 ? 2 : 4)>(a, g, B, heads, stream);
   }
   if (g.nsplit > 1) {
     const size_t n4 = per_sample / 4 + 1;
@@ -537,11 +537,14 @@ extern "C" int hdiff_mha_flash_bwd(const float* qkv, const float* o, const float
   switch (D) {
     case 4: return launch_bwd<4>(qkv, o, d_o, lse2, delta, dqkv, ws, B, C, heads, L, s);
     case 8: return launch_bwd<8>(qkv, o, d_o, lse2, delta, dqkv, ws, B, C, heads, L, s);
+    case 12: return launch_bwd<12>(qkv, o, d_o, lse2, delta, dqkv, ws, B, C, heads, L, s);
     case 16: return launch_bwd<16>(qkv, o, d_o, lse2, delta, dqkv, ws, B, C, heads, L, s);
+    case 24: return launch_bwd<24>(qkv, o, d_o, lse2, delta, dqkv, ws, B, C, heads, L, s);
     case 32: return launch_bwd<32>(qkv, o, d_o, lse2, delta, dqkv, ws, B, C, heads, L, s);
+    case 48: return launch_bwd<48>(qkv, o, d_o, lse2, delta, dqkv, ws, B, C, heads, L, s);
     case 64: return launch_bwd<64>(qkv, o, d_o, lse2, delta, dqkv, ws, B, C, heads, L, s);
     default: break;
   }
-  hdiff::set_error("mha_flash_bwd: head dim %d not in {4, 8, 16, 32, 64}", D);
+  hdiff::set_error("mha_flash_bwd: head dim %d not in {4, 8, 12, 16, 24, 32, 48, 64}", D);
   return HDIFF_ERR_INVALID;
 }

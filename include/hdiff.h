@@ -165,7 +165,7 @@ int hdiff_gn_swish_apply(const float* x, const float* scale, const float* shift,
  * Multi-head self-attention core (K9).  Replaces the softmax(QK^T/sqrt(d))V of nn.MultiheadAttention(C, 8) called as
  * attn(h,h,h) at ModelCondition.py:189,204-208.  qkv is the output of the packed in-projection viewed as a 1x1 conv:
  * [B][3C][L] with rows [Q | K | V], head h owning rows h*d..h*d+d-1 of each third.  o is [B][C][L].
- * Flash style: the L x L score matrix is never materialised.  d = C/heads must be one of 4, 8, 16, 32, 64 (64: slower one-tile-per-wave kernels; not a shape of the default model).
+ * Flash style: the L x L score matrix is never materialised.  d = C/heads must be one of 4, 8, 12, 16, 24, 32, 48, 64 (48 / 64: slower one-tile-per-wave kernels; not shapes of the default model).
  * ------------------------------------------------------------------------------------------------------------------ */
 int hdiff_mha_flash_fwd(const float* qkv, float* o, float* lse2 /*[B][heads][L] or NULL*/, int B, int C, int heads, int L,
                         hdiff_stream_t stream);

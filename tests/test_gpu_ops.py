@@ -137,7 +137,8 @@ def attention_core_ref(qkv, heads):
 
 
 @pytest.mark.parametrize("d,L,B", [(4, 64, 2), (8, 256, 1), (16, 64, 2), (16, 1024, 1), (32, 36, 2), (32, 576, 1),
-                                   (16, 4096, 1), (32, 1000, 1), (8, 37, 1), (64, 256, 1), (64, 77, 2)])
+                                   (16, 4096, 1), (32, 1000, 1), (8, 37, 1), (64, 256, 1), (64, 77, 2),
+                                   (12, 1024, 1), (12, 50, 2), (24, 1024, 1), (24, 333, 1), (48, 512, 1), (48, 91, 2)])
 def test_flash_attention_core(d, L, B):
     g = torch.Generator().manual_seed(d * 7 + L)
     heads = 8
