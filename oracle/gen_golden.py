@@ -14,6 +14,8 @@ Fixtures:
   G2b attnblock.npz       AttnBlock (dead code in the reference's UNet) at 64 channels (flash path) and 128 (wide-head path)
                           [python -m oracle.gen_golden g2b]
   G3 unet_small.npz       small UNet (ch=32, ch_mult=[1,2], nrb=1): state_dict, inputs, eps @16^2 and @32^2, per-layer taps
+  G3c unet_wide.npz       four levels, ch=32 ch_mult=[1,2,3,4] (attention heads of 4 / 8 / 12 / 16 channels) @32^2 B=2: seed recipe,
+                          weight checksums, eps; trainer loss + gradients of ten tensors      [python -m oracle.gen_golden g3c]
   G4 unet_default64.npz   default UNet (ch=128,[1,2,2,2],nrb=2) @64^2 B=1: seed recipe, weight checksums, input, eps
   G4b unet_default128.npz default UNet @128^2 B=1 (BASELINE config C2's shape; the reference materialises 8 x 16384^2 scores
                           = 8.6 GB per attention block): input, eps for label 1 and label 0   [python -m oracle.gen_golden g4b]
@@ -42,8 +44,10 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 SMALL = dict(T=8, num_labels=3, ch=32, ch_mult=[1, 2], num_res_blocks=1, dropout=0.0)
 DEFAULT = dict(T=1000, num_labels=10, ch=128, ch_mult=[1, 2, 2, 2], num_res_blocks=2, dropout=0.15)
+WIDE = dict(T=16, num_labels=3, ch=32, ch_mult=[1, 2, 3, 4], num_res_blocks=1, dropout=0.0)   # head widths 4, 8, 12, 16
 SMALL_SEED = 1234
 DEFAULT_SEED = 0
+WIDE_SEED = 31
 
 
 def _np(t):
@@ -348,6 +352,49 @@ def gen_trainer_small(RM, RD):
     np.savez_compressed(os.path.join(OUT, "trainer_small.npz"), **out)
 
 
+def gen_unet_wide(RM, RD):
+    """G3c: four resolution levels with widths 32 / 64 / 96 / 128 (8 heads of 4 / 8 / 12 / 16 channels) from the REAL
+    reference: eval forward at 32x32, and one trainer pass (loss, a few gradients, total norm).  Weights come from the seed
+    recipe (pinned by checksums), plus a seeded perturbation of the zero-initialised MHA biases."""
+    def build():
+        torch.manual_seed(WIDE_SEED)
+        m = RM.UNet(**WIDE)
+        g = torch.Generator().manual_seed(WIDE_SEED + 1)
+        with torch.no_grad():
+            for n, p in sorted(m.named_parameters()):
+                if n.endswith("in_proj_bias") or n.endswith("out_proj.bias"):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        return m
+    m = build().eval()
+    names, sums = weight_checksums(m.state_dict())
+    g = torch.Generator().manual_seed(515)
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    t, labels = torch.tensor([5, 11]), torch.tensor([3, 0])
+    out = {"seed": np.array([WIDE_SEED]), "cfg_json": np.frombuffer(json.dumps(WIDE).encode(), dtype=np.uint8),
+           "weight_names": np.array(names), "weight_checksums": sums, "x": _np(x), "t": _np(t), "labels": _np(labels),
+           "temb_rows": _np(m.time_embedding.timembedding[0].weight)}
+    with torch.no_grad():
+        out["eps"] = _np(m(x, t, labels))
+    m.train()
+    trainer = RD.GaussianDiffusionTrainer(m, 1e-4, 0.02, WIDE["T"])
+    x_0 = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    tl = torch.tensor([1, 2])
+    torch.manual_seed(616)
+    with _Recorder() as rec:
+        loss = trainer(x_0, tl)
+    (loss.sum() / 2 ** 2.).backward()
+    out.update({"x_0": _np(x_0), "train_labels": _np(tl), "train_t": _np(rec.randint[0]), "noise": _np(rec.randn[0]),
+                "loss": _np(loss)})
+    params = dict(m.named_parameters())
+    for n in ["head.weight", "downblocks.0.attn.in_proj_weight", "downblocks.2.attn.in_proj_weight",
+              "downblocks.4.attn.in_proj_weight", "downblocks.4.attn.out_proj.weight", "downblocks.6.attn.in_proj_weight",
+              "middleblocks.0.attn.in_proj_bias", "downblocks.4.block1.2.weight", "upblocks.3.shortcut.weight",
+              "tail.2.weight"]:
+        out[f"grad/{n}"] = _np(params[n].grad)
+    out["grad_total_norm"] = np.array([torch.nn.utils.clip_grad_norm_(m.parameters(), 1e9).item()])
+    np.savez_compressed(os.path.join(OUT, "unet_wide.npz"), **out)
+
+
 def gen_lr_schedule():
     RS = RL.load_scheduler()
     p = torch.nn.Parameter(torch.zeros(1))
@@ -378,6 +425,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g2b":
         gen_attnblock(RM)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g3c":
+        gen_unet_wide(RM, RD)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g5b":
         gen_sampler_default128(RM, RD)

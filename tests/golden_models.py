@@ -1,0 +1,41 @@
+"""Models whose weights are not stored with their golden vectors but rebuilt from the seed recipe of oracle/gen_golden.py
+(the build's UNet initialises bit-identically to the reference under the same torch seed; checksums pin it)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def state_checksums(sd):
+    names = sorted(sd.keys())
+    rows = []
+    for n in names:
+        bits = sd[n].detach().float().contiguous().reshape(-1).view(torch.int32).to(torch.int64)
+        rows.append([int(bits.sum().item()), bits.numel(), int(bits[0].item()), int(bits[-1].item())])
+    return names, np.array(rows, dtype=np.int64)
+
+
+def wide_model(UNet):
+    """G3c (tests/golden/unet_wide.npz): ch = 32, ch_mult = [1, 2, 3, 4] -> attention heads of 4 / 8 / 12 / 16 channels.
+    Returns (model on the CPU in eval mode, config dict, npz)."""
+    d = np.load(os.path.join(GOLDEN, "unet_wide.npz"))
+    c = json.loads(bytes(d["cfg_json"]).decode())
+    seed = int(d["seed"][0])
+    torch.manual_seed(seed)
+    m = UNet(**c)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in sorted(m.named_parameters()):
+            if n.endswith("in_proj_bias") or n.endswith("out_proj.bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        table = "time_embedding.timembedding.0.weight"      # sin/cos table: last-bit differences between CPU generations
+        assert (m.state_dict()[table] - torch.from_numpy(d["temb_rows"])).abs().max().item() < 1e-5
+        m.time_embedding.timembedding[0].weight.copy_(torch.from_numpy(d["temb_rows"]))
+    names, sums = state_checksums(m.state_dict())
+    assert list(d["weight_names"]) == names
+    bad = [n for n, a, b in zip(names, sums, d["weight_checksums"]) if not np.array_equal(a, b)]
+    assert not bad, f"seed recipe no longer reproduces the reference init for {bad[:8]} ({len(bad)} tensors)"
+    return m.eval(), c, d

@@ -255,6 +255,34 @@ def test_unet_with_d_head_64_vs_oracle():
                if "cond_embedding.condEmbedding.0" not in n)
 
 
+def test_unet_wide_levels_golden_forward_and_training():
+    """G3c from the REAL reference: ch_mult [1, 2, 3, 4] at ch = 32 (attention heads of 4, 8, 12 and 16 channels, three
+    down / up samplings): eval forward, then the trainer's loss and gradients (TrainCondition.py:59-60)."""
+    from golden_models import wide_model
+    m, c, d = wide_model(MC.UNet)
+    m = m.to(DEV)
+    with torch.no_grad():
+        y = m(T(d["x"]).to(DEV), T(d["t"]).to(DEV), T(d["labels"]).to(DEV))
+    e = maxerr(y, T(d["eps"]))
+    print(f"unet_wide max err {e:.3e}")
+    assert e < 2e-4
+    m.train()
+    tr = DC.GaussianDiffusionTrainer(m, 1e-4, 0.02, c["T"]).to(DEV)
+    x_0 = T(d["x_0"]).to(DEV)
+    loss = tr(x_0, T(d["train_labels"]).to(DEV), t=T(d["train_t"]).to(DEV), noise=T(d["noise"]).to(DEV))
+    ref = T(d["loss"])
+    assert maxerr(loss, ref) < 1e-3 * ref.abs().max().item()
+    (loss.sum() / x_0.shape[0] ** 2.).backward()
+    params = dict(m.named_parameters())
+    for key in [k for k in d.files if k.startswith("grad/")]:
+        ref = T(d[key])
+        err = maxerr(params[key[5:]].grad, ref) / (ref.abs().max().item() + 1e-12)
+        print(f"grad {key[5:]}: rel err {err:.2e}")
+        assert err < 1e-3, (key, err)
+    total = torch.nn.utils.clip_grad_norm_(m.parameters(), 1e9).item()
+    assert abs(total / float(d["grad_total_norm"][0]) - 1.0) < 1e-3
+
+
 def test_attn_block_against_golden():
     """AttnBlock: one head as wide as the block (64 channels -> flash kernel with heads = 1; 128 -> the wide-head kernel),
     GroupNorm without Swish, residual; against the reference's recorded outputs."""

@@ -148,3 +148,15 @@ def test_oracle_vs_live_reference_default64():
                        num_res_blocks=c["num_res_blocks"], dropout=c["dropout"])
     y = O.unet_forward(dict(m.state_dict()), cfg, T(d["x"]), T(d["t"]), torch.tensor([1]))
     assert torch.allclose(y, T(d["eps_label1"]), atol=1e-4)
+
+
+def test_oracle_wide_model_against_reference_golden():
+    """G3c: four levels, widths 32 / 64 / 96 / 128 = heads of 4 / 8 / 12 / 16 channels; the REAL reference's eps for weights
+    rebuilt from the seed recipe (checksummed).  Runs without the reference: the build's UNet is only constructed here."""
+    from hdiff_amd.DiffusionFreeGuidence import ModelCondition as MC
+    from golden_models import wide_model
+    m, c, d = wide_model(MC.UNet)
+    cfg = O.UNetConfig(T=c["T"], num_labels=c["num_labels"], ch=c["ch"], ch_mult=tuple(c["ch_mult"]),
+                       num_res_blocks=c["num_res_blocks"], dropout=c["dropout"])
+    y = O.unet_forward(dict(m.state_dict()), cfg, T(d["x"]), T(d["t"]), T(d["labels"]))
+    assert (y - T(d["eps"])).abs().max().item() < 5e-5
