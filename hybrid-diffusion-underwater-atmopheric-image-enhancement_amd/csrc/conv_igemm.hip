@@ -59,11 +59,12 @@ __device__ __forceinline__ float swish_fast(float v) { return v * __builtin_amdg
 // parameter (not a runtime test) matters: a branch inside the unrolled MFMA loop stops the compiler from hoisting the LDS
 // operand reads across k-steps (it does not change the measured rate: the kernel is not bound by those reads).
 template <int WN, int CK, int NXS, int NWS, int SPEC, bool TWOM>
-__global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(NTHREADS, (CK == 8 ? 2 : 1)) void conv_igemm_kernel(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sX = smem;                       // [CK][PLANE]
   float* sW = smem + p.XFLOATS;           // [ntaps][CK][BM]
   float* sG = sW + p.WFLOATS;             // [2][Cin]: GroupNorm scale | shift of this sample
+  float* sE = sG + 2 * p.Cin;             // [2][BM]: bias | per-sample vector of the block's channels (the uniform epilogue)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -128,6 +129,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   if (has_gn) {
     for (int i = tid; i < 2 * p.Cin; i += NTHREADS)
       sG[i] = (i < p.Cin) ? p.gn_scale[b * p.Cin + i] : p.gn_shift[b * p.Cin + (i - p.Cin)];
+  }
+  if (tid < 2 * BM) {
+    const int co = co0 + (tid & (BM - 1));
+    const float* src = (tid < BM) ? p.bias : p.addvec;
+    sE[tid] = (src != nullptr && co < p.Cout) ? src[(tid < BM ? 0 : (size_t)b * p.Cout) + co] : 0.f;
   }
   // tap offsets live across the lanes of one register: read back with v_readlane (no memory access in the MFMA loop)
   const int tapv = (lane < p.ntaps) ? p.tap_off[lane] : 0;
@@ -285,6 +291,68 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvK p) {
   // element) was ~25 VALU instructions per output element -- 0.7 per MFMA of a 128-channel conv, none of it overlappable.
   const bool full_block = (co0 + BM <= p.Cout);      // every channel row of the block exists (all but the 3-channel tail conv)
   const int co_lim = p.Cout - co0;
+  if constexpr (TWOM) {
+    // Whole tile inside the output, whole channel block, one K slice (a workgroup-uniform test): no per-lane control flow, so
+    // the residual / bias / vector loads of ALL of the wave's accumulator registers are in flight together before the first
+    // add (the per-pixel-tile form below waits for one tile's loads, stores, and only then starts the next tile's loads).
+    if (full_block && p.ksplit == 1 && vy0 + p.TH <= p.VH && vx0 + TWm1 < p.VW) {
+      const int plane = p.OH * p.OW;
+      const bool has_bias = p.bias != nullptr, has_vec = p.addvec != nullptr;
+      size_t blk[WN];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) {
+        const int pidx = (wave * WN + nt) * 32 + l31;
+        const int vy = vy0 + (pidx >> p.tw_log2), vx = vx0 + (pidx & TWm1);
+        blk[nt] = ((size_t)b * p.Cout + co0) * (size_t)plane + (vy * p.out_sy + p.out_oy) * p.OW + (vx * p.out_sx + p.out_ox);
+      }
+      float res[WN][2][16];
+      if (p.residual) {
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+          const float* rbase = p.residual + blk[nt];
+          int rel = 4 * h * plane;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              res[nt][mt][r] = rbase[rel];
+              rel += ((r & 3) == 3) ? 5 * plane : plane;
+            }
+        }
+      }
+      // bias and vector of the block's channel rows from LDS (staged with the GroupNorm table): same order of additions as the
+      // general form -- (acc + bias) + vector, then + residual
+      const float* sEh = sE + 4 * h;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mt * 32 + (r & 3) + 8 * (r >> 2);
+          const float bv = sEh[row], vv = sEh[BM + row];
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) {
+            float v = acc[mt][nt][r];
+            if (has_bias) v += bv;
+            if (has_vec) v += vv;
+            if (p.residual) v += res[nt][mt][r];
+            acc[mt][nt][r] = v;
+          }
+        }
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) {
+        float* obase = p.out + blk[nt];
+        int rel = 4 * h * plane;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            obase[rel] = acc[mt][nt][r];
+            rel += ((r & 3) == 3) ? 5 * plane : plane;
+          }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int nt = 0; nt < WN; ++nt) {
     const int pidx = (wave * WN + nt) * 32 + l31;
@@ -487,7 +555,7 @@ int configure(const hdiff_conv_desc* d, ConvCfg& c) {
   auto slots_w = [&](int ck) { return cdiv(d->ntaps * ck * (BM / 4), NTHREADS); };
   auto lds_for = [&](int ck) {
     const int xfl = (ck * k.PLANE + 3) & ~3;
-    return (size_t)(xfl + d->ntaps * ck * BM + 2 * Cin) * sizeof(float);
+    return (size_t)(xfl + d->ntaps * ck * BM + 2 * Cin + 2 * BM) * sizeof(float);
   };
   c.CK = 0;
   if (slots_x(8) <= 12 && slots_w(8) <= 5 && lds_for(8) <= 64 * 1024 && (d->C1 == 0 || d->C0 % 8 == 0)) c.CK = 8;
