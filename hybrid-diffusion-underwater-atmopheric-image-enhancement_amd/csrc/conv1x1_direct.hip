@@ -34,6 +34,7 @@ struct Conv1x1K {
 namespace {
 
 constexpr int THREADS = 256;
+constexpr int EC = 8;     // channel rows per epilogue group
 constexpr int U = 2;      // k-steps per software-pipeline stage (4 measured no faster)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -46,12 +47,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // concat seam: the activation base pointer is wave-uniform), CoutPad % 64 == 0, weight rows [Cin, CinPad) zero
 // (hdiff_pack_conv_weight).  Every load is unconditional: an odd Cin's phantom channel is clamped onto the last real one
 // and meets a zero weight row.
-__global__ __launch_bounds__(THREADS) void conv1x1_direct_kernel(const Conv1x1K p) {
+__global__ __launch_bounds__(THREADS, 2) void conv1x1_direct_kernel(const Conv1x1K p) {
   constexpr int MT = 2, WN = 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int co0 = blockIdx.x * 64;
-  const long px0 = ((long)blockIdx.y * 4 + wave) * 128;
+  const long px0 = ((long)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(wave)) * 128;      // wave-uniform, in SGPRs
   const int b = blockIdx.z;
   if (px0 >= p.HW) return;                      // whole wave out of range (no barriers in this kernel)
   const int C1 = p.Cin - p.C0;
@@ -101,6 +102,44 @@ __global__ __launch_bounds__(THREADS) void conv1x1_direct_kernel(const Conv1x1K 
       if (k2 + U + u < K2) mma(fb[u]);
   }
 
+  // ---- epilogue.  A full 64-channel block (a wave-uniform test: everything but a tail block) takes the branch-free form:
+  // the bias / vector / residual loads of EC channel rows are in flight together before the first add -- with the
+  // per-row channel test every row waited for its own three loads in turn (32 dependent round trips per wave).
+  if (co0 + 64 <= p.Cout) {
+    // addresses = wave-uniform base (scalar registers) + one 32-bit lane offset: channel row 8h of the block, pixel 4*l31
+    const size_t blk = ((size_t)b * p.Cout + co0) * p.HW + px0;
+    const unsigned lane_row = 8u * h, lane_off = lane_row * hw + 4u * l31;
+    const float* biasu = p.bias ? p.bias + co0 : nullptr;
+    const float* vecu = p.addvec ? p.addvec + (size_t)b * p.Cout + co0 : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += EC) {
+        f32x4 res[EC];
+        float add[EC];
+#pragma unroll
+        for (int j = 0; j < EC; ++j) {
+          const int r = r0 + j;
+          const int rowc = 2 * (r & 3) + 16 * (r >> 2) + mt;             // compile-time part of the channel row
+          float a = 0.f;
+          if (biasu) a += biasu[rowc + lane_row];
+          if (vecu) a += vecu[rowc + lane_row];
+          add[j] = a;
+          if (p.residual) res[j] = *reinterpret_cast<const f32x4*>(p.residual + blk + (size_t)rowc * p.HW + lane_off);
+        }
+#pragma unroll
+        for (int j = 0; j < EC; ++j) {
+          const int r = r0 + j;
+          const int rowc = 2 * (r & 3) + 16 * (r >> 2) + mt;
+          f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+          v += add[j];
+          if (p.residual) v += res[j];
+          *reinterpret_cast<f32x4*>(p.out + blk + (size_t)rowc * p.HW + lane_off) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep the next group's loads below: the register budget is three waves per SIMD
+      }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

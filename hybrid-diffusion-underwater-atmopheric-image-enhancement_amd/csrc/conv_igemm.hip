@@ -59,7 +59,7 @@ __device__ __forceinline__ float swish_fast(float v) { return v * __builtin_amdg
 // parameter (not a runtime test) matters: a branch inside the unrolled MFMA loop stops the compiler from hoisting the LDS
 // operand reads across k-steps (it does not change the measured rate: the kernel is not bound by those reads).
 template <int WN, int CK, int NXS, int NWS, int SPEC, bool TWOM>
-__global__ __launch_bounds__(NTHREADS, (CK == 8 ? 2 : 1)) void conv_igemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sX = smem;                       // [CK][PLANE]
   float* sW = smem + p.XFLOATS;           // [ntaps][CK][BM]
