@@ -145,6 +145,9 @@ class FlatGradients:
             if p.grad is None or p.grad.data_ptr() != self.views[i].data_ptr():     # the view was replaced behind our back: exchange_mean_ repairs and starts it
                 return
             b = self._owner[i]
+            if b < self._next:
+                raise RuntimeError("FlatGradients(overlap=True): a gradient arrived after its bucket had been sent -- one "
+                                   "backward per zero_() / exchange_mean_(); accumulate over several backwards with overlap=False")
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._ready[b] = True
