@@ -10,7 +10,8 @@ DDP with one process per GPU (utils/rotinas.py:572-577, 619).  The hot path shar
   reduced with reduce-scatter + all-gather (every link busy at once) rather than a ring all-reduce of small buckets.
   The gradients live as views in that flat buffer (FlatGradients): no gather / scatter copies around the exchange, and
   the reduce-scatter of each 64 MB bucket starts from a gradient hook while backward is still running.
-  NO scaling curve has been measured yet (the build box has one GPU; the driver's 8-GPU run was skipped in round 1).
+  NO scaling curve has been measured yet (the build box has one GPU; the driver's 8-GPU run was skipped in round 1);
+  RCCL has executed this exchange in a one-rank group on the GPU, gloo with two ranks (tests/).
 """
 from __future__ import annotations
 
@@ -93,7 +94,7 @@ class FlatGradients:
     """
 
     def __init__(self, params: Sequence[torch.nn.Parameter], world: int | None = None, overlap: bool = False,
-                 bucket_bytes: int = 64 << 20):
+                 bucket_bytes: int = 64 << 20, single_rank_collectives: bool = False):
         self.params = [p for p in params if p.requires_grad]
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         w = self.world
@@ -123,7 +124,11 @@ class FlatGradients:
         self._count = [0] * len(self.buckets)
         for b in owner:
             self._count[b] += 1
-        self.overlap = bool(overlap) and w > 1
+        # single_rank_collectives: issue the collectives even in a one-rank group (tests: the RCCL calls, their stream
+        # ordering against the backward kernels and the hook threading run on the one GPU of the build box; the mean over
+        # one rank must give the gradients back bit for bit)
+        self.single = bool(single_rank_collectives)
+        self.overlap = bool(overlap) and (w > 1 or self.single)
         self._pending: List[int] = []
         self._ready: List[bool] = []
         self._work: list = []
@@ -171,7 +176,7 @@ class FlatGradients:
 
     def exchange_mean_(self) -> int:
         """Returns the bytes each rank contributes to the exchange (0 when there is nothing to exchange)."""
-        if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
+        if (self.world == 1 and not self.single) or not (dist.is_available() and dist.is_initialized()):
             return 0
         started = self._next
         for i, (p, v) in enumerate(zip(self.params, self.views)):

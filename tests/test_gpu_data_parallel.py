@@ -80,3 +80,64 @@ def test_two_ranks_train_identical_replicas_on_one_gpu():
         assert err <= 1e-6 * mag + 1e-12, (err, mag)       # exchanged gradient = mean of the ranks' own gradients
         assert sent >= 4 * 800_000                            # the whole flat buffer (0.88 M parameters) went through the collective
     assert (w0 == w1).all(), "replicas diverged"
+
+
+def _rccl_worker(port, q):
+    """One rank, backend "nccl" (= RCCL): the training step's exchange with the REAL collective library -- asynchronous
+    reduce-scatters started from the gradient hooks inside backward, all-gathers at the end.  The mean over one rank must
+    give back exactly the gradients a plain backward produces; a collective that ran ahead of the kernels writing its
+    bucket (wrong stream ordering) would return stale values."""
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import hdiff_amd  # noqa: F401
+    from hdiff_amd import parallel as P
+    from hdiff_amd.DiffusionFreeGuidence.DiffusionCondition import GaussianDiffusionTrainer
+    from hdiff_amd.DiffusionFreeGuidence.ModelCondition import UNet
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(5)
+        net = UNet(T=8, num_labels=3, ch=32, ch_mult=[1, 2], num_res_blocks=1, dropout=0.0).to(dev).train()
+        tr = GaussianDiffusionTrainer(net, 1e-4, 0.02, 8).to(dev)
+        weights = list(net.parameters())
+        g = torch.Generator().manual_seed(11)
+        x0 = (torch.rand(2, 3, 32, 32, generator=g) * 2 - 1).to(dev)
+        labels, t = torch.tensor([1, 2], device=dev), torch.tensor([3, 5], device=dev)
+        noise = torch.randn(2, 3, 32, 32, generator=g).to(dev)
+
+        def loss():
+            return tr(x0, labels, t=t, noise=noise).sum() / 2 ** 2.
+        for p in weights:
+            p.grad = None
+        loss().backward()
+        plain = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in weights]).clone()
+        flat = P.FlatGradients(weights, 1, overlap=True, bucket_bytes=1 << 20, single_rank_collectives=True)
+        out = []
+        for step in range(2):
+            flat.zero_()
+            loss().backward()
+            started = flat._next
+            sent = flat.exchange_mean_()
+            got = torch.cat([p.grad.reshape(-1) for p in weights])
+            out.append((started, len(flat.buckets), sent, bool(torch.equal(got, plain)), float((got - plain).abs().max())))
+        q.put(("ok", dist.get_backend(), out))
+        dist.destroy_process_group()
+    except Exception as e:           # report instead of hanging the parent on the queue
+        q.put(("error", repr(e), []))
+
+
+def test_rccl_single_rank_runs_the_bucketed_exchange_on_the_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    status, backend, out = q.get(timeout=300)
+    p.join(120)
+    assert status == "ok", backend
+    assert backend == "nccl"
+    for started, nb, sent, same, err in out:
+        assert nb >= 3 and started >= 1                      # buckets left from the hooks while backward was running
+        assert sent >= 4 * 800_000
+        assert same, f"RCCL exchange over one rank changed the gradients (max diff {err})"
