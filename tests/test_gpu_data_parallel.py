@@ -122,6 +122,22 @@ def _rccl_worker(port, q):
             sent = flat.exchange_mean_()
             got = torch.cat([p.grad.reshape(-1) for p in weights])
             out.append((started, len(flat.buckets), sent, bool(torch.equal(got, plain)), float((got - plain).abs().max())))
+        # what bench.py --gpus N does on every rank: capture the sampler step into a hipGraph and replay it while the
+        # RCCL group (and its watchdog thread) is alive, a barrier and a MAX all-reduce around it
+        from hdiff_amd.DiffusionFreeGuidence.DiffusionCondition import GaussianDiffusionSampler
+        net.eval()
+        sm = GaussianDiffusionSampler(net, 1e-4, 0.02, 8, w=1.8).to(dev)
+        xT = torch.randn(2, 3, 32, 32, generator=g).to(dev)
+        z = torch.randn(8, 2, 3, 32, 32, generator=g).to(dev)
+        with torch.no_grad():
+            sm.use_graph = False
+            eager = sm(xT, labels, noise_by_step=z)
+            sm.use_graph = True
+            dist.barrier()
+            graphed = sm(xT, labels, noise_by_step=z)
+        tmax = torch.tensor([1.5], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        out.append(("sampler", bool(torch.equal(eager, graphed)), float(tmax.item())))
         q.put(("ok", dist.get_backend(), out))
         dist.destroy_process_group()
     except Exception as e:           # report instead of hanging the parent on the queue
@@ -137,6 +153,8 @@ def test_rccl_single_rank_runs_the_bucketed_exchange_on_the_gpu():
     p.join(120)
     assert status == "ok", backend
     assert backend == "nccl"
+    tag, same_sample, tmax = out.pop()
+    assert tag == "sampler" and same_sample and tmax == 1.5     # graph capture / replay beside the live RCCL group
     for started, nb, sent, same, err in out:
         assert nb >= 3 and started >= 1                      # buckets left from the hooks while backward was running
         assert sent >= 4 * 800_000
