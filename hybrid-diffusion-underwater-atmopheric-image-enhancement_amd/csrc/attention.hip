@@ -368,6 +368,20 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
     for (int mt = 0; mt < MT; ++mt) O[mt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  // P of the query tile in flight; its row sums are added one query tile LATE (see softmax), so it outlives do_tile
+  f32x4 P[4];
+  auto rowsum = [&](int qt) {
+    // the tile's row sums as PACKED adds on register-quad halves: v_pk_add_f32 as inline asm because the compiler scalarises
+    // these vector adds (34 scalar + 19 packed adds per 64x64 scores in the element-wise form; every VALU instruction is
+    // issue time taken from the fp32 MFMA stream).  A tree, not a chain: the compiler puts one wait state between an asm
+    // statement and an asm statement reading its result, and the tree has two such adjacent pairs where the chain had seven.
+    const f32x2 a = pk_add(__builtin_shufflevector(P[0], P[0], 0, 1), __builtin_shufflevector(P[0], P[0], 2, 3));
+    const f32x2 b = pk_add(__builtin_shufflevector(P[1], P[1], 0, 1), __builtin_shufflevector(P[1], P[1], 2, 3));
+    const f32x2 c = pk_add(__builtin_shufflevector(P[2], P[2], 0, 1), __builtin_shufflevector(P[2], P[2], 2, 3));
+    const f32x2 d = pk_add(__builtin_shufflevector(P[3], P[3], 0, 1), __builtin_shufflevector(P[3], P[3], 2, 3));
+    const f32x2 ab = pk_add(a, b), cd = pk_add(c, d);
+    l_run[qt] = pk_add(l_run[qt], pk_add(ab, cd));    // packed running sums, folded after the last tile
+  };
   auto do_tile = [&](auto first_tag, int buf) {
     constexpr bool FIRST = decltype(first_tag)::value;
     float kf[4][KS];
@@ -383,7 +397,6 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
       }
     }
     f32x4 S[2][4];
-    f32x4 P[4];
     auto qk_mfma = [&](int qt, int i) {
       const int s = i >> 2, ks = i & 3;
       // the chain starts from -m1 (zero on the first tile), so the accumulator already holds s - m1
@@ -406,34 +419,42 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) Sq[ks] += negm4[qt];
       }
-      // P as whole register quads, then the tile's row sums as PACKED adds on their halves: two v_pk_add_f32 per 16-key
-      // subtile, as inline asm because the compiler scalarises these vector adds (34 scalar + 19 packed adds per 64x64 scores
-      // in the element-wise form; every VALU instruction is issue time taken from the fp32 MFMA stream).
-      // gfx950 needs one wait state between a transcendental (v_exp_f32) and a VALU instruction reading its result, and the
-      // compiler's hazard recogniser does not look inside asm statements: all sixteen v_exp of the query tile are issued first
-      // and pinned above the adds, whose first reader of any v_exp result is then >= 1 instruction away
-      // (tests/test_host_cpu.py disassembles the library and checks exactly that).
+      // Order per query tile: [all MFMAs issued so far] | row sums of the PREVIOUS query tile's P | the 16 exps | MFMAs.
+      // * The MFMAs stay above: left alone, the compiler hoists each key subtile's exps to just behind the last MFMA of that
+      //   subtile's chain and pays the MFMA -> VALU result hazard in s_nop (two s_nop 8 and three s_nop 4-5 per query tile).
+      // * The previous tile's row sums (its P is still in registers; they read no MFMA result) fill what is left of that
+      //   hazard window, so no s_nop is issued at all, and they are nowhere near a v_exp_f32 writing their sources: gfx950
+      //   needs one wait state between a transcendental and a VALU instruction reading its result, and the compiler's hazard
+      //   recogniser does not look inside asm statements (tests/test_host_cpu.py disassembles the library and checks that).
+      if (!FIRST || qt > 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        rowsum((qt + NQ - 1) % NQ);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
         P[ks] = f32x4{__builtin_amdgcn_exp2f(Sq[ks][0]), __builtin_amdgcn_exp2f(Sq[ks][1]), __builtin_amdgcn_exp2f(Sq[ks][2]),
                       __builtin_amdgcn_exp2f(Sq[ks][3])};
       __builtin_amdgcn_sched_barrier(0);
-      f32x2 sum2 = pk_add(__builtin_shufflevector(P[0], P[0], 0, 1), __builtin_shufflevector(P[0], P[0], 2, 3));
-#pragma unroll
-      for (int ks = 1; ks < 4; ++ks)
-        sum2 = pk_add(pk_add(sum2, __builtin_shufflevector(P[ks], P[ks], 0, 1)), __builtin_shufflevector(P[ks], P[ks], 2, 3));
-      l_run[qt] += sum2;    // packed running sums (tile sums first: shorter rounding chains), folded after the last tile
     };
 #pragma unroll
     for (int i = 0; i < N_QK; ++i) qk_mfma(0, i);
 #pragma unroll
     for (int qt = 0; qt < NQ; ++qt) {
       softmax(qt);
-      constexpr int NMAX = (N_QK > N_PV) ? N_QK : N_PV;
+      // P.V(qt) alternates with QK^T(qt + 1), which leads by LEAD slots, and the last LEAD MFMAs of the group are fenced off
+      // as P.V's: LEAD MFMAs plus the 8 row-sum adds then separate the last QK^T MFMA from the first exp that reads a score
+      // -- the 11 wait states of the MFMA -> VALU result hazard without a single s_nop.
+      constexpr int LEAD = 3;
+      static_assert(N_QK <= N_PV, "the QK^T chain is folded into the P.V slots");
+      if (qt + 1 < NQ) {
 #pragma unroll
-      for (int i = 0; i < NMAX; ++i) {
-        if (i < N_PV) pv_mfma(qt, i);
-        if (qt + 1 < NQ && i < N_QK) qk_mfma(qt + 1, i);
+        for (int i = 0; i < LEAD; ++i) qk_mfma(qt + 1, i);
+      }
+#pragma unroll
+      for (int i = 0; i < N_PV; ++i) {
+        if (i == N_PV - LEAD) __builtin_amdgcn_sched_barrier(0);
+        pv_mfma(qt, i);
+        if (qt + 1 < NQ && i + LEAD < N_QK) qk_mfma(qt + 1, i + LEAD);
       }
     }
   };
@@ -453,6 +474,7 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
     stage_store(buf ^ 1);
     __syncthreads();
   }
+  rowsum(NQ - 1);      // the last query tile's sums of the last key tile
 
   float* obase = out + ((size_t)b * C + (size_t)head * D) * L;
 #pragma unroll
