@@ -311,8 +311,10 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   const TileId tile = xcd_tile();
-  const int head = tile.head, b = tile.b;
-  const int qblk0 = tile.x * QB + wave * (16 * NQ);
+  // the tile coordinates come out of integer divisions the compiler evaluates on the vector ALU: moved to scalar registers, so
+  // that everything derived from them (the K / V base pointers of the staging loads) is scalar too
+  const int head = __builtin_amdgcn_readfirstlane(tile.head), b = __builtin_amdgcn_readfirstlane(tile.b);
+  const int qblk0 = __builtin_amdgcn_readfirstlane(tile.x) * QB + wave * (16 * NQ);
   const float* qbase = qkv + ((size_t)b * 3 * C + (size_t)head * D) * L;
   const float* kbase = qbase + (size_t)C * L;
   const float* vbase = kbase + (size_t)C * L;
@@ -334,14 +336,33 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
   }
 
   f32x4 stage[NLD];
+  // d_head >= 16: a staging slot (256 consecutive 16-byte pieces = 16 rows) lies entirely in K or entirely in V, so it is
+  // read with buffer loads: resource = the head's K (or V) rows, vector offset = the lane's fixed byte offset, SCALAR offset =
+  // the tile -- no vector address arithmetic in the loop (a 64-bit v_lshl_add_u64 per slot and tile with flat pointers: the
+  // compiler folds the lane offset into the pointer and re-adds the tile offset on the vector ALU)
+  constexpr bool UNIFORM_SLOTS = (D % 16 == 0);
+  const __amdgpu_buffer_rsrc_t rsrcK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kbase), 0, D * L * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vbase), 0, D * L * 4, 0x00020000);
+  unsigned lane_off[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = tid + i * ATT_THREADS, row = idx >> 4, seg = idx & 15;
+    lane_off[i] = (unsigned)((row < D ? row : row - D) * L + seg * 4) * 4u;      // bytes (< 2^32: 32 rows of L floats)
+  }
   auto stage_load = [&](int t) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + i * ATT_THREADS;
       if (NV4 % ATT_THREADS == 0 || idx < NV4) {
         const int row = idx >> 4, seg = idx & 15;
-        const float* src = (row < D ? kbase + (size_t)row * L : vbase + (size_t)(row - D) * L) + t * KT + seg * 4;
-        stage[i] = *reinterpret_cast<const f32x4*>(src);
+        if constexpr (UNIFORM_SLOTS) {
+          const bool is_k = ((i * ATT_THREADS) >> 4) < D;                         // compile-time choice per slot
+          stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(is_k ? rsrcK : rsrcV, lane_off[i],
+                                                                                     t * (KT * 4), 0));
+        } else {
+          const float* src = (row < D ? kbase + (size_t)row * L : vbase + (size_t)(row - D) * L) + t * KT + seg * 4;
+          stage[i] = *reinterpret_cast<const f32x4*>(src);
+        }
       }
     }
   };
@@ -467,13 +488,22 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
   do_tile(std::true_type{}, 0);
   stage_store(1);
   __syncthreads();
-  for (int t = 1; t < ntiles; ++t) {
-    const int buf = t & 1;
+  // two tiles per iteration, so that the LDS buffer index is a compile-time constant: every LDS address of the body is a
+  // fixed base register + immediate (with a run-time buffer index the compiler re-bases them on the vector ALU, ten
+  // v_add_u32 per tile at d_head 16 -- issue time the fp32 MFMA stream cannot overlap)
+  auto step = [&](int t, auto buf_tag) {
+    constexpr int buf = decltype(buf_tag)::value;
     stage_load((t + 1 < ntiles) ? t + 1 : t);
     do_tile(std::false_type{}, buf);
     stage_store(buf ^ 1);
     __syncthreads();
+  };
+  int t = 1;
+  for (; t + 1 < ntiles; t += 2) {
+    step(t, std::integral_constant<int, 1>{});
+    step(t + 1, std::integral_constant<int, 0>{});
   }
+  if (t < ntiles) step(t, std::integral_constant<int, 1>{});
   rowsum(NQ - 1);      // the last query tile's sums of the last key tile
 
   float* obase = out + ((size_t)b * C + (size_t)head * D) * L;
