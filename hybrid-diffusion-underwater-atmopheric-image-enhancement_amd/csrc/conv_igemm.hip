@@ -88,19 +88,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvK p) 
   // of a mask, and the GroupNorm scale / shift of the thread are two registers per chunk.  (PMC, round 2: the generic slot
   // scheme below costs 2.3 VALU instructions per MFMA -- 13 % of the kernel's time, all of it taken from the matrix pipe.)
   const int s_ci = tid >> 5;
-  unsigned s_out = 0;  // SPEC: bit i: slot i is zero padding (outside the image) -- its load goes to a safe offset
+  // SPEC: slot i is zero padding (outside the image) -- its load goes to a safe offset and its value is replaced by 0.  One
+  // bool per slot: the compiler keeps each as a lane mask in a scalar register pair, so the replacement is ONE v_cndmask per
+  // element (packed into a bit mask they cost a shift, an and and a compare per element on top -- VALU issue time that the
+  // fp32 MFMA stream cannot overlap).  Slots 0..9 of the 340-element patch exist for every lane, slot 10 for lanes < 20.
+  constexpr int SPEC_SLOTS = 11;
+  bool s_outb[SPEC_SLOTS];
+  const bool s_last = (tid & 31) < 340 - 320;
   if constexpr (SPEC == 1) {
+    static_assert(NXS >= SPEC_SLOTS, "the 3x3 patch needs 11 slots per thread");
     const int safe = vy0 * p.W + vx0;
 #pragma unroll
-    for (int i = 0; i < NXS; ++i) {
+    for (int i = 0; i < SPEC_SLOTS; ++i) {
       const int m = (tid & 31) + 32 * i;
       const int py = m / 34, px = m - py * 34;
       const int iy = iy0 + py, ix = ix0 + px;
       const bool in_patch = m < 340;
       const bool in_img = in_patch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      x_soff[i] = in_img ? iy * p.W + ix : safe;
-      x_meta[i] = in_patch ? s_ci * 350 + py * 35 + px : -1;
-      s_out |= (in_img ? 0u : 1u) << i;
+      x_soff[i] = 4 * ((in_img ? iy * p.W + ix : safe) + s_ci * (int)HW);     // BYTE offset inside the chunk (buffer loads)
+      x_meta[i] = s_ci * 350 + py * 35 + px;
+      s_outb[i] = !in_img;
     }
   } else {
     const int plane_elems = p.PH * p.PW;
@@ -158,17 +165,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvK p) 
 
   float xr[NXS];
   float4 wr[NWS];
-  unsigned s_dead = 0;   // SPEC: all ones when this thread's channel of the chunk in flight does not exist (Cin % 8 != 0)
+  // SPEC: buffer resources of this sample's input tensors (range = the sample's channels: reads past Cin return 0)
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x0 + (size_t)b * p.C0 * HW), 0, p.C0 * (int)HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x1 ? p.x1 + (size_t)b * p.C1 * HW : p.x0), 0, p.x1 ? p.C1 * (int)HW * 4 : 0, 0x00020000);
   auto issue_loads = [&](int c0) {
     // a chunk never straddles the concat seam (C0 % CK == 0 is checked on the host)
     const float* xbase = (c0 < p.C0) ? p.x0 + ((size_t)b * p.C0 + c0) * HW : p.x1 + ((size_t)b * p.C1 + (c0 - p.C0)) * HW;
     const int c_left = p.Cin - c0;     // channels of this chunk that exist
     if constexpr (SPEC == 1) {
-      const bool live = s_ci < c_left;
-      s_dead = live ? 0u : ~0u;
-      const float* xs = xbase + (size_t)(live ? s_ci : 0) * HW;        // a missing channel reads channel 0 and is zeroed
+      // buffer loads: resource = this sample's x0 (or x1) tensor, vector offset = the slot's fixed byte offset, SCALAR offset =
+      // the chunk -- no vector address arithmetic per load (a 64-bit multiply-add per slot with flat pointers).  A channel
+      // past Cin (Cin % 8 != 0) lies beyond the resource and reads as 0; its GroupNorm scale / shift are zeroed below.
+      const bool first = c0 < p.C0;
+      const int soff = (first ? c0 : c0 - p.C0) * (int)HW * 4;
 #pragma unroll
-      for (int i = 0; i < NXS; ++i) xr[i] = xs[x_soff[i]];
+      for (int i = 0; i < SPEC_SLOTS; ++i)
+        xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(first ? rsrc0 : rsrc1, x_soff[i], soff, 0));
     } else {
 #pragma unroll
       for (int i = 0; i < NXS; ++i) {
@@ -184,19 +198,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvK p) 
   auto store_staged = [&](int c0) {
     const int c_left = p.Cin - c0;
     if constexpr (SPEC == 1) {
-      float gsc = 1.f, gsh = 0.f;
-      if (has_gn && s_ci < c_left) {
-        gsc = sG[c0 + s_ci];
-        gsh = sG[p.Cin + c0 + s_ci];
-      }
-      const unsigned zero = s_out | s_dead;
+      const bool live = s_ci < c_left;        // a channel past Cin was read as 0 (buffer range) and must stay 0 after Swish
+      if (has_gn) {
+        const float gsc = live ? sG[c0 + s_ci] : 0.f, gsh = live ? sG[p.Cin + c0 + s_ci] : 0.f;
 #pragma unroll
-      for (int i = 0; i < NXS; ++i) {
-        if (x_meta[i] >= 0) {
-          float v = xr[i];
-          if (has_gn) v = swish_fast(fmaf(v, gsc, gsh));
-          sX[x_meta[i]] = ((zero >> i) & 1u) ? 0.f : v;               // the conv pads the ACTIVATED tensor with zeros
+        for (int i = 0; i < SPEC_SLOTS; ++i) {
+          const float v = swish_fast(fmaf(xr[i], gsc, gsh));
+          if (i < SPEC_SLOTS - 1 || s_last) sX[x_meta[i]] = s_outb[i] ? 0.f : v;     // the conv pads the ACTIVATED tensor with zeros
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < SPEC_SLOTS; ++i)
+          if (i < SPEC_SLOTS - 1 || s_last) sX[x_meta[i]] = s_outb[i] ? 0.f : xr[i];
       }
     } else {
 #pragma unroll
@@ -690,6 +703,9 @@ extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream)
   // the specialised 3x3 path: standard taps in row-major order, stride 1, 8x32 tile (patch stride 35, plane 350)
   bool spec = c.WN == 2 && c.CK == 8 && d->ntaps == 9 && d->in_stride == 1 && k.tw_log2 == 5 && k.PWp == 35 && k.PLANE == 350;
   for (int t = 0; spec && t < 9; ++t) spec = k.tap_off[t] == (t / 3) * 35 + (t % 3);
+  // the specialised kernel addresses a sample's input tensor through a buffer resource with 32-bit byte offsets
+  const long long hw = (long long)d->H * d->W;
+  if (4 * hw * (d->C0 > d->C1 ? d->C0 : d->C1) >= (1ll << 31)) spec = false;
   if (spec) return launch<2, 8, 12, 5, 1>(k, d->B, c.lds, s);
   if (c.WN == 2 && c.CK == 8) return launch<2, 8, 12, 5, 0>(k, d->B, c.lds, s);
   if (c.WN == 2 && c.CK == 4) return launch<2, 4, 20, 7, 0>(k, d->B, c.lds, s);
