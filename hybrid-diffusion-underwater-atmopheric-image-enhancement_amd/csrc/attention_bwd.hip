@@ -102,6 +102,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 48 ? 1 : 2)) void mha_bwd_fused_
   constexpr bool OLD_EARLY = (MT == 1);
   constexpr bool OPS_AHEAD = (MT == 1);           // operands of the next query subtile fetched during the current one
   constexpr bool PIPELINED = (MT == 1) && FAST && (NK >= 2);   // chains of the next pair issued ahead of this pair's VALU step (d_head 32: 47 spilled registers with the second S / dP pair)
+  constexpr bool TWO_AHEAD = FAST && (MT == 1) && (NK % 2 == 0);   // query-tile loads two tiles ahead (ntiles = L / 64 is then even)
   constexpr bool KT_FENCE = (MT > 1);             // d_head 32: keep the key tiles' MFMA groups apart (register budget, see do_tile)
 
   __shared__ __attribute__((aligned(16))) float sQ[2][DP * KROW];
@@ -141,9 +142,10 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 48 ? 1 : 2)) void mha_bwd_fused_
   }
 
   // ---- staging of one 64-query tile: global -> registers (before the MFMA work) -> LDS (after it)
-  float4 stage[NLD];
-  float4 stage_ld = make_float4(0.f, 0.f, 0.f, 0.f);
-  int stage_col = 0;
+  struct Stage { float4 v[NLD]; float4 ld; int col; };
+  Stage st0, st1;            // st1: second register set of the two-tiles-ahead loop (TWO_AHEAD below)
+  st0.ld = st1.ld = make_float4(0.f, 0.f, 0.f, 0.f);
+  st0.col = st1.col = 0;
   auto load4 = [&](const float* src, int col) {
     if (FAST) return *reinterpret_cast<const float4*>(src);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 48 ? 1 : 2)) void mha_bwd_fused_
     }
     return v;
   };
-  auto stage_load = [&](int t) {
+  auto stage_load = [&](Stage& st, int t) {
     const int q0 = t * KT;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -165,33 +167,33 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 48 ? 1 : 2)) void mha_bwd_fused_
       if (idx < NV4) {
         const int row = idx >> 4, col = q0 + (idx & 15) * 4;
         const float* src = (row < D ? qbase + (size_t)row * L : dobase + (size_t)(row - D) * L) + col;
-        stage[i] = load4(src, col);
+        st.v[i] = load4(src, col);
       }
     }
     if (tid < 32) {
       const int col = q0 + (tid & 15) * 4;
-      stage_ld = load4((tid < 16 ? lbase : dbase) + col, col);     // negated when it is stored (no wait on the load here)
-      stage_col = col;
+      st.ld = load4((tid < 16 ? lbase : dbase) + col, col);     // negated when it is stored (no wait on the load here)
+      st.col = col;
     }
   };
-  auto stage_store = [&](int buf) {
+  auto stage_store = [&](const Stage& st, int buf) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + i * ATT_THREADS;
       if (idx < NV4) {
         const int row = idx >> 4, seg = idx & 15;
         float* dst = (row < D) ? &sQ[buf][row * KROW + seg * 4] : &sO[buf][(row - D) * KROW + seg * 4];
-        *reinterpret_cast<float4*>(dst) = stage[i];
+        *reinterpret_cast<float4*>(dst) = st.v[i];
       }
     }
     if (tid < 32) {
-      float4 v = make_float4(-stage_ld.x, -stage_ld.y, -stage_ld.z, -stage_ld.w);
+      float4 v = make_float4(-st.ld.x, -st.ld.y, -st.ld.z, -st.ld.w);
       if (!FAST && tid < 16) {
         // -lse2 is -inf for queries beyond L: p = exp2(s - inf) = 0 there
-        if (stage_col + 0 >= L) v.x = -__builtin_inff();
-        if (stage_col + 1 >= L) v.y = -__builtin_inff();
-        if (stage_col + 2 >= L) v.z = -__builtin_inff();
-        if (stage_col + 3 >= L) v.w = -__builtin_inff();
+        if (st.col + 0 >= L) v.x = -__builtin_inff();
+        if (st.col + 1 >= L) v.y = -__builtin_inff();
+        if (st.col + 2 >= L) v.z = -__builtin_inff();
+        if (st.col + 3 >= L) v.w = -__builtin_inff();
       }
       *reinterpret_cast<float4*>(tid < 16 ? &sL[buf][tid * 4] : &sD[buf][(tid - 16) * 4]) = v;
     }
@@ -375,18 +377,15 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 48 ? 1 : 2)) void mha_bwd_fused_
       }
     };
 
-    __syncthreads();              // the previous key block's last tile is fully consumed (LDS buffers are reused)
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-      const int buf = t & 1, dqbuf = (DQ_BUFS == 2) ? (t & 1) : 0;
-      const int tn = (t + 1 < ntiles) ? t + 1 : t;     // the last iteration re-stages its own tile (branch-free; unused)
-      stage_load(tn);
+    // One tile of the sweep: start the global loads of tile t_ld into `ld`, fetch the running dQ partial, do the MFMA work of
+    // tile t (LDS buffer buf), publish the tile held in `stf` to the other LDS buffer, then reduce this tile's dQ.
+    auto tile_step = [&](int t, int buf, int dqbuf, Stage& ld, int t_ld, const Stage& stf) {
+      stage_load(ld, t_ld);
       // this thread's share of the running dQ partial of tile t: rows d = idx / 16, queries 4 * (idx % 16) ..+3.
       // d_head <= 16: fetched before the MFMA work; d_head 32 has no registers to hold it that long and fetches it behind
-      // (the co-resident workgroup's waves cover the wait)
+      // (the co-resident workgroup's waves cover the wait).  The slab is streamed (each line is touched once per key block,
+      // 4 MB of other slab lines later): non-temporal loads / stores keep it from evicting the Q / dO tiles that the 32
+      // workgroups of a (head, sample) pair share through L2 / Infinity Cache.
       float4 old[MT];
       auto fetch_old = [&]() {
 #pragma unroll
@@ -394,14 +393,21 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 48 ? 1 : 2)) void mha_bwd_fused_
           const int idx = tid + i * ATT_THREADS;
           const int d = idx >> 4, q = t * KT + (idx & 15) * 4;
           old[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (!first_block && d < D) old[i] = load4(part + (size_t)d * L + q, q);
+          if (!first_block && d < D) {
+            if (FAST) {
+              const f32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(part + (size_t)d * L + q));
+              old[i] = make_float4(nv[0], nv[1], nv[2], nv[3]);
+            } else {
+              old[i] = load4(part + (size_t)d * L + q, q);
+            }
+          }
         }
       };
       if (OLD_EARLY) fetch_old();
       if (!FAST && ragged_keys) do_tile(std::true_type{}, buf, dqbuf);
       else do_tile(std::false_type{}, buf, dqbuf);
       if (!OLD_EARLY) fetch_old();
-      stage_store(buf ^ 1);
+      stage_store(stf, buf ^ 1);
       __syncthreads();
       // sum the four waves' partial tiles in wave order, add the running value, store
 #pragma unroll
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 48 ? 1 : 2)) void mha_bwd_fused_
         if (d < D) {
           float* dst = part + (size_t)d * L + q;
           if (FAST) {
-            *reinterpret_cast<float4*>(dst) = acc;
+            __builtin_nontemporal_store(f32x4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<f32x4*>(dst));
           } else if (vec_ok) {
             if (q < L) *reinterpret_cast<float4*>(dst) = acc;
           } else {
@@ -429,6 +435,29 @@ __global__ __launch_bounds__(ATT_THREADS, (D >= 48 ? 1 : 2)) void mha_bwd_fused_
         }
       }
       if (DQ_BUFS == 1) __syncthreads();
+    };
+
+    __syncthreads();              // the previous key block's last tile is fully consumed (LDS buffers are reused)
+    stage_load(st0, 0);
+    stage_store(st0, 0);
+    __syncthreads();
+    if constexpr (TWO_AHEAD) {
+      // Global loads run TWO tiles ahead on two register sets, two tiles per iteration (ntiles is even here): with the dQ
+      // slab traffic in the memory system a Q / dO tile load takes longer than one tile of MFMA work (timing ablations:
+      // without the slab traffic, or with the tile loads hitting in cache, the kernel is 5 % faster; one tile ahead the
+      // wave stalls at the s_waitcnt in front of the LDS store).  The LDS / dQ buffer indices become compile-time constants.
+      const int last = ntiles - 1;
+      stage_load(st0, 1 < last ? 1 : last);
+      for (int t = 0; t < ntiles; t += 2) {
+        tile_step(t, 0, 0, st1, t + 2 < last ? t + 2 : last, st0);          // st0 holds tile t + 1
+        tile_step(t + 1, 1, 1, st0, t + 3 < last ? t + 3 : last, st1);      // st1 holds tile t + 2
+      }
+    } else {
+      for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, dqbuf = (DQ_BUFS == 2) ? (t & 1) : 0;
+        const int tn = (t + 1 < ntiles) ? t + 1 : t;     // the last iteration re-stages its own tile (branch-free; unused)
+        tile_step(t, buf, dqbuf, st0, tn, st0);
+      }
     }
 
     // ---- dK, dV of this key block (complete: the sweep covered every query)
