@@ -134,7 +134,9 @@ def attention_ref(qkv, heads):
 
 @pytest.mark.parametrize("d,H,W,B", [(4, 8, 8, 2), (8, 6, 6, 2), (16, 16, 16, 1), (16, 32, 32, 1), (32, 24, 24, 1), (32, 5, 7, 1),
                                      (64, 16, 16, 1), (64, 5, 9, 2), (16, 72, 72, 1), (32, 80, 80, 1),
-                                     (12, 72, 72, 1), (12, 5, 7, 2), (24, 80, 80, 1), (24, 9, 5, 1), (48, 16, 16, 1), (48, 5, 9, 2)])
+                                     (12, 72, 72, 1), (12, 5, 7, 2), (24, 80, 80, 1), (24, 9, 5, 1), (48, 16, 16, 1), (48, 5, 9, 2),
+                                     # L = 5120 = 20 x 256: four key tiles per wave, query-tile loads two tiles ahead (d <= 16)
+                                     (16, 64, 80, 1), (12, 64, 80, 1), (8, 64, 80, 1)])
 def test_flash_attention_backward(d, H, W, B):
     g = torch.Generator().manual_seed(d + H)
     Cc = 8 * d
