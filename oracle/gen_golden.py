@@ -24,6 +24,8 @@ Fixtures:
                           [python -m oracle.gen_golden g5b; ~8 min, ~25 GB]
   G5 sampler_small.npz    T=8 sampler on the small UNet, w in {0, 1.8}: x_T, per-step noise, pre-clip trajectory, output
   G6 trainer_small.npz    Trainer loss with recorded (t, noise); grads of named params; one clipped AdamW step
+  G6b trainer_default64.npz  the DEFAULT model's trainer pass at 64x64, B = 2 (attention backward over L = 4096, d_head 16 / 32):
+                          loss, 19 small gradient tensors + 4 row slices, total norm         [python -m oracle.gen_golden g6b]
   G7 state_dict_default.json   the 366 (name, shape) pairs of the default UNet
   G8 lr_schedule.json     GradualWarmupScheduler + CosineAnnealingLR learning-rate sequence (Scheduler.py)
 """
@@ -395,6 +397,48 @@ def gen_unet_wide(RM, RD):
     np.savez_compressed(os.path.join(OUT, "unet_wide.npz"), **out)
 
 
+def gen_trainer_default64(RM, RD):
+    """G6b: one trainer pass of the DEFAULT model (ch=128, [1,2,2,2], d_head 16 / 32; attention over L = 4096 at the first
+    level) from the REAL reference at 64x64, B = 2: loss, gradients of small tensors from every part of the network, the
+    total gradient norm.  dropout = 0 (torch's CPU dropout stream cannot be reproduced by a device generator); weights from
+    the seed recipe + the seeded perturbation of the zero-initialised MHA biases used by G3c."""
+    cfg = dict(DEFAULT, dropout=0.0)
+    torch.manual_seed(DEFAULT_SEED)
+    m = RM.UNet(**cfg)
+    g = torch.Generator().manual_seed(DEFAULT_SEED + 1)
+    with torch.no_grad():
+        for n, p in sorted(m.named_parameters()):
+            if n.endswith("in_proj_bias") or n.endswith("out_proj.bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    m.train()
+    trainer = RD.GaussianDiffusionTrainer(m, 1e-4, 0.02, cfg["T"])
+    gx = torch.Generator().manual_seed(2024)
+    x_0 = torch.rand(2, 3, 64, 64, generator=gx) * 2 - 1
+    labels = torch.tensor([1, 2])
+    torch.manual_seed(99)
+    with _Recorder() as rec:
+        loss = trainer(x_0, labels)
+    (loss.sum() / 2 ** 2.).backward()
+    out = {"seed": np.array([DEFAULT_SEED]), "cfg_json": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+           "x_0": _np(x_0), "labels": _np(labels), "t": _np(rec.randint[0]), "noise": _np(rec.randn[0]), "loss": _np(loss),
+           "temb_rows": _np(m.time_embedding.timembedding[0].weight[rec.randint[0]])}
+    params = dict(m.named_parameters())
+    names = ["head.bias", "tail.2.weight", "tail.0.weight", "time_embedding.timembedding.3.bias",
+             "cond_embedding.condEmbedding.3.bias", "downblocks.0.block1.0.weight", "downblocks.0.attn.in_proj_bias",
+             "downblocks.0.attn.out_proj.bias", "downblocks.1.block2.3.bias", "downblocks.2.c1.bias",
+             "downblocks.3.shortcut.bias", "downblocks.3.attn.in_proj_bias", "downblocks.4.temb_proj.1.bias",
+             "middleblocks.0.attn.in_proj_bias", "middleblocks.1.cond_proj.1.bias", "upblocks.0.block1.0.bias",
+             "upblocks.3.t.bias", "upblocks.14.block2.0.weight", "upblocks.14.shortcut.bias"]
+    for n in names:
+        out[f"grad/{n}"] = _np(params[n].grad)
+    # slices of large tensors: the first 4 output rows
+    for n in ["downblocks.0.attn.in_proj_weight", "downblocks.3.attn.in_proj_weight", "downblocks.0.block1.2.weight",
+              "upblocks.14.block1.2.weight"]:
+        out[f"gradrows/{n}"] = _np(params[n].grad[:4])
+    out["grad_total_norm"] = np.array([torch.nn.utils.clip_grad_norm_(m.parameters(), 1e9).item()])
+    np.savez_compressed(os.path.join(OUT, "trainer_default64.npz"), **out)
+
+
 def gen_lr_schedule():
     RS = RL.load_scheduler()
     p = torch.nn.Parameter(torch.zeros(1))
@@ -425,6 +469,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g2b":
         gen_attnblock(RM)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g6b":
+        gen_trainer_default64(RM, RD)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g3c":
         gen_unet_wide(RM, RD)

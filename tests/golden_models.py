@@ -39,3 +39,25 @@ def wide_model(UNet):
     bad = [n for n, a, b in zip(names, sums, d["weight_checksums"]) if not np.array_equal(a, b)]
     assert not bad, f"seed recipe no longer reproduces the reference init for {bad[:8]} ({len(bad)} tensors)"
     return m.eval(), c, d
+
+
+def default_trainer_model(UNet):
+    """G6b (tests/golden/trainer_default64.npz): the default configuration with dropout 0, weights from the seed recipe of G4
+    (torch.manual_seed(seed); the checksums of G4 pin that init) plus the seeded MHA-bias perturbation; the sinusoidal rows
+    the recorded time steps use come from the fixture (last-bit differences between CPU generations).
+    Returns (model on the CPU in train mode, config dict, npz)."""
+    d = np.load(os.path.join(GOLDEN, "trainer_default64.npz"))
+    c = json.loads(bytes(d["cfg_json"]).decode())
+    seed = int(d["seed"][0])
+    torch.manual_seed(seed)
+    m = UNet(**c)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in sorted(m.named_parameters()):
+            if n.endswith("in_proj_bias") or n.endswith("out_proj.bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        rows = torch.from_numpy(d["temb_rows"])
+        for i, t in enumerate(d["t"].tolist()):
+            assert (m.time_embedding.timembedding[0].weight[t] - rows[i]).abs().max().item() < 1e-3
+            m.time_embedding.timembedding[0].weight[t].copy_(rows[i])
+    return m.train(), c, d

@@ -281,3 +281,32 @@ def test_training_step_on_tiny_images_matches_oracle_autograd():
         e_cpu = (grads["f32"][0][n] - ref).abs().max().item()
         e_hip = (params[n].grad.detach().cpu().double() - ref).abs().max().item()
         assert e_hip <= 4 * e_cpu + 1e-6 * scale, (n, e_hip, e_cpu, scale)
+
+
+def test_default_model_trainer_gradients_golden():
+    """G6b: loss and gradients of the DEFAULT model (d_head 16 / 32; attention backward over L = 4096, 1024, 256, 64) recorded
+    from the REAL reference at 64x64, B = 2 (TrainCondition.py:59-60): 19 small gradient tensors from every part of the
+    network, 4 row slices of large ones, and the total gradient norm over all 366 tensors."""
+    from golden_models import default_trainer_model
+    m, c, d = default_trainer_model(MC.UNet)
+    m = m.to(DEV)
+    tr = DC.GaussianDiffusionTrainer(m, 1e-4, 0.02, c["T"]).to(DEV)
+    x_0 = T(d["x_0"]).to(DEV)
+    loss = tr(x_0, T(d["labels"]).to(DEV), t=T(d["t"]).to(DEV), noise=T(d["noise"]).to(DEV))
+    close(loss, T(d["loss"]), rel=1e-3, what="loss")
+    (loss.sum() / x_0.shape[0] ** 2.).backward()
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for key in [k for k in d.files if k.startswith("grad/") or k.startswith("gradrows/")]:
+        name = key.split("/", 1)[1]
+        ref = T(d[key])
+        got = params[name].grad.cpu()
+        if key.startswith("gradrows/"):
+            got = got[:4]
+        err = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        worst = max(worst, err)
+        print(f"grad {name}: rel err {err:.2e}")
+        assert err < 1e-3, (name, err)
+    total = torch.nn.utils.clip_grad_norm_(m.parameters(), 1e9).item()
+    assert abs(total / float(d["grad_total_norm"][0]) - 1.0) < 1e-3
+    print("worst relative gradient error", worst)
