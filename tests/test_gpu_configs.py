@@ -170,6 +170,42 @@ def test_c3_attention_backward_full_length(Cc, L, scale):
     assert torch.equal(dqkv3, dqkv)
 
 
+def test_c3_trainer_gradients_128_against_the_pinned_oracle():
+    """One trainer pass of the default model at 128x128, B = 1 (attention backward over L = 16 384 at d_head 16 -- four key
+    tiles per wave, the two-tiles-ahead path -- and L = 4096 at d_head 32): loss and EVERY parameter gradient against the CPU
+    oracle differentiated by torch autograd.  That oracle is pinned for this model's training pass by the real reference's
+    recorded gradients at 64x64 (tests/test_oracle_golden.py, G6b)."""
+    from golden_models import default_trainer_model
+    m, c, _ = default_trainer_model(MC.UNet)
+    cfg = O.UNetConfig(T=c["T"], num_labels=c["num_labels"], ch=c["ch"], ch_mult=tuple(c["ch_mult"]),
+                       num_res_blocks=c["num_res_blocks"], dropout=0.0)
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.rand(1, 3, 128, 128, generator=g) * 2 - 1
+    noise = torch.randn(1, 3, 128, 128, generator=g)
+    t, labels = torch.tensor([401]), torch.tensor([2])          # a time step whose sinusoidal row the fixture pinned
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    betas = torch.linspace(1e-4, 0.02, c["T"]).double()
+    ab = torch.cumprod(1.0 - betas, dim=0)
+    x_t = torch.sqrt(ab)[t].float().view(-1, 1, 1, 1) * x0 + torch.sqrt(1.0 - ab)[t].float().view(-1, 1, 1, 1) * noise
+    ref_loss = (O.unet_forward(sd, cfg, x_t, t, labels) - noise) ** 2
+    ref_loss.sum().backward()
+    md = m.to(DEV)
+    tr = DC.GaussianDiffusionTrainer(md, 1e-4, 0.02, c["T"]).to(DEV)
+    loss = tr(x0.to(DEV), labels.to(DEV), t=t.to(DEV), noise=noise.to(DEV))
+    assert maxerr(loss, ref_loss) < 1e-3 * ref_loss.abs().max().item()
+    loss.sum().backward()
+    worst, n = 0.0, 0
+    for name, p in md.named_parameters():
+        ref = sd[name].grad
+        if ref is None or ref.abs().max().item() == 0.0:
+            continue
+        err = maxerr(p.grad, ref) / ref.abs().max().item()
+        worst, n = max(worst, err), n + 1
+        assert err < 1e-3, (name, err)
+    assert n >= 360                                              # every tensor of the network (the padding row aside)
+    print(f"128x128 trainer pass: {n} gradient tensors, worst relative error {worst:.2e}")
+
+
 @pytest.mark.parametrize("C0,C1,cout", [(128, 0, 128), (256, 128, 128)])
 def test_c3_conv_backward_256(C0, C1, cout):
     """The fused GroupNorm-Swish-conv3x3 backward at 256x256 (B = 2): weight gradient at sampled (co, ci) pairs (all nine
