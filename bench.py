@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: denoising-steps/sec of the CFG-DDPM sampler at 256x256 on the T=1000 schedule.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 with no launcher: this process (which never touches the GPU) starts N fresh rank processes itself
+(hdiff_amd.parallel.launch_ranks -- the reference's other tree does the same with mp.spawn, utils/rotinas.py:572-577),
+waits, relays rank 0's ONE JSON line and exits non-zero if any rank does.  Under ``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`` the ranks are already there (WORLD_SIZE is set) and each runs its share.
+Either way one rank per GPU over RCCL, and the run refuses to time anything unless WORLD_SIZE == --gpus.
 
 One "step" = one iteration of the reference sampler loop (DiffusionCondition.py:87-96) for the whole per-GPU batch:
 cond + uncond UNet forward (one 2B-batched launch sequence) + fused CFG/posterior update.  Inputs (x_T, labels, weights)
@@ -9,18 +15,26 @@ are resident in HBM before the timed region.  Sampling shards by image: every ra
 and there is no data-path collective (weak scaling); value = N * K / max-over-ranks wall time.
 
 The timed region replays the hipGraph-captured step (the north-star formulation; ``--eager`` times plain launches instead).
-Per-kernel durations come from a second pass of the same K steps issued as plain launches with HIP events recorded on the
-launch stream around the launches of interest (events cannot bracket nodes inside a graph replay; the kernels, their
-arguments and their order are identical -- the two passes agree to < 0.1 % at this size, both wall times are reported).
+Per-kernel durations come from a second pass of the same K steps (same start state, same time steps) issued as plain
+launches with HIP events recorded on the launch stream around the launches of interest (events cannot bracket nodes
+inside a graph replay; the kernels, their arguments and their order are identical -- the two passes agree to < 0.1 % at
+this size, both wall times are reported).
 
 Rank 0 prints ONE JSON line with the contract keys plus
   roofline      dominant kernel (flash attention at L = 65536, d_head = 16) against the fp32-MFMA peak; ``secondary`` holds
-                the full-resolution 3x3 convolution (MFMA) and the GroupNorm statistics pass (HBM) the same way
+                the full-resolution 3x3 convolution (MFMA) and the GroupNorm statistics pass (HBM) the same way;
+                ``traffic`` comes from profiles/roofline_traffic.json and is reported only while the kernel sources still
+                hash to what that file was measured on (``traffic_stamp``)
   cpu_baseline  the CPU oracle (oracle/cpu_path.py, kind "port"): one whole UNet forward at 128x128 timed on the host
-                cores (a bounded sample, ~25 s), scaled to the benchmark's step by the algorithmic FLOP ratio
+                cores (a bounded sample), scaled to the benchmark's step by the algorithmic FLOP ratio; ``same_config``
+                holds the one BASELINE config the CPU finishes in full (C1), timed on both sides
+  parity        max-abs / PSNR of the HIP path against the oracle on the inputs the two legs above computed anyway
+  configs       the other BASELINE configs on this GPU (N = 1 only; never part of ``value``): C1 in full, C2 20 steps,
+                C5 one step of one GPU's share, C3 one optimizer step (``--no-extras`` skips them)
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -30,7 +44,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+import torch  # noqa: E402   (importing torch does not initialise the GPU)
 
 MODEL = dict(T=1000, num_labels=10, ch=128, ch_mult=[1, 2, 2, 2], num_res_blocks=2, dropout=0.15)
 BETA = (1e-4, 0.02)
@@ -40,9 +54,10 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6    # MI355X_MICROARCH.md: dense bf16 MFMA peak (n
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak (spec); ~6.3 TB/s is what a float4 copy achieves
 # algorithmic FLOPs per sample per UNet forward (torch flop counter on the reference UNet)
 FWD_GFLOP = {64: 74.0, 128: 529.6, 256: 5857.4, 512: 83254.1}
+CSRC = os.path.join(ROOT, "hybrid-diffusion-underwater-atmopheric-image-enhancement_amd", "csrc")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -56,48 +71,310 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time plain launches instead of the hipGraph replay")
     ap.add_argument("--graph", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second, event-instrumented pass (no roofline)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the other BASELINE configs (C1 full on GPU and CPU, C2, C5, C3) reported under `configs`")
+    ap.add_argument("--extras-scale", choices=["full", "small"], default="full",
+                    help="dev/tests: `small` runs the `configs` legs at toy sizes so that the code path finishes in seconds")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="dev: run the N > 1 code path (rendezvous, barriers, max over ranks, aggregation) with every rank on "
                          "cuda:0 over gloo -- RCCL refuses two ranks on one device; the numbers mean nothing")
-    return ap.parse_args()
+    a = ap.parse_args(argv)
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    # three passes (timed, event-instrumented, other contraction mode) each start from step T-1: K + W steps must fit
+    if a.steps + a.warmup + 1 > MODEL["T"]:
+        ap.error(f"--steps + --warmup must stay below T = {MODEL['T']}")
+    return a
 
 
-def cpu_baseline(size, batch):
-    """Oracle on the host cores: ONE whole UNet forward at 128x128, B = 1 (the largest size that finishes in tens of
-    seconds; attention is 60 % of its FLOPs against 85 % at 256x256), scaled to one denoising step of the benchmark
-    (2 * batch forwards at `size`) by the algorithmic FLOP ratio."""
-    from oracle import cpu_path as O
-    threads = min(os.cpu_count() or 1, 16)          # the one-GPU box's CPU share
-    torch.set_num_threads(threads)
+# ----------------------------------------------------------------------------------------------------------------------
+# helpers shared by the headline and the `configs` legs
+# ----------------------------------------------------------------------------------------------------------------------
+def _model(cfg, dev, train=False):
     from hdiff_amd.DiffusionFreeGuidence.ModelCondition import UNet
-    torch.manual_seed(0)
-    m = UNet(**MODEL).eval()
+    torch.manual_seed(0)                              # same weights on every rank (replicated model) and on the CPU side
+    m = UNet(**cfg)
+    return (m.train() if train else m.eval()).to(dev)
+
+
+def _oracle_cfg(cfg):
+    from oracle import cpu_path as O
+    return O.UNetConfig(T=cfg["T"], num_labels=cfg["num_labels"], ch=cfg["ch"], ch_mult=tuple(cfg["ch_mult"]),
+                        num_res_blocks=cfg["num_res_blocks"])
+
+
+def _host_threads():
+    threads = min(os.cpu_count() or 1, 16)            # the one-GPU box's CPU share
+    torch.set_num_threads(threads)
+    return threads
+
+
+def _quality(a, b):
+    """PSNR (dB) / SSIM of two [-1, 1] image batches on the reference's evaluation scale (x*0.5+0.5, utils/rotinas.py:922-926)."""
+    from hdiff_amd import metrics as M
+    ia = ((a.cpu().clamp(-1, 1) * 0.5 + 0.5) * 255.0).permute(0, 2, 3, 1).numpy()
+    ib = ((b.cpu().clamp(-1, 1) * 0.5 + 0.5) * 255.0).permute(0, 2, 3, 1).numpy()
+    return (min(M.psnr(x, y, 255) for x, y in zip(ia, ib)),
+            min(M.ssim(x, y, 255, channel_axis=2) for x, y in zip(ia, ib)))
+
+
+def _release():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def time_sampler_steps(model, size, batch, T, beta, w, steps, warmup, dev, seed=1234, graph=True):
+    """K replays of the captured denoising step at (size, batch) after W warm-up replays; returns seconds per step."""
+    from hdiff_amd.DiffusionFreeGuidence.DiffusionCondition import GaussianDiffusionSampler, _SamplerPlan
+    sampler = GaussianDiffusionSampler(model, beta[0], beta[1], T, w=w).to(dev)
+    g = torch.Generator().manual_seed(seed)
+    x_T = torch.randn(batch, 3, size, size, generator=g).to(dev)
+    labels = (torch.arange(batch) % 2 + 1).to(dev)
+    with torch.no_grad():
+        sp = _SamplerPlan(sampler, batch, size, size, dev)
+        plan = sp.variant(False, seed)
+        sp.unet.plan.pack_weights()
+        sp.x.copy_(x_T)
+        sp.unet.labels.copy_(torch.cat([labels, torch.zeros_like(labels)]))
+        sp.step.fill_(T - 1)
+        sp.nan_flag.zero_()
+        if graph:
+            plan.capture()
+        run = plan.replay if graph else plan.run
+        for _ in range(warmup):
+            run()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        assert int(sp.nan_flag.item()) == 0, "nan in tensor."
+        mem = sp.unet.plan.bytes_allocated()
+    del plan, sp, sampler
+    return dt, mem
+
+
+def train_steps(size, batch, steps, warmup, dropout, dev, rank=0, world=1, rehearse=False, model_cfg=None):
+    """Optimizer steps of the CFG-DDPM trainer on the HIP path: forward + hand-written backward [+ the one gradient exchange
+    of data-parallel training] + clip_grad_norm_ + AdamW (TrainCondition.py:59-63).  Returns a dict for the JSON line."""
+    from hdiff_amd import parallel
+    from hdiff_amd.DiffusionFreeGuidence.DiffusionCondition import GaussianDiffusionTrainer
+    m = _model(dict(model_cfg or MODEL, dropout=dropout), dev, train=True)
+    parallel.broadcast_parameters_(m.parameters())
+    tr = GaussianDiffusionTrainer(m, BETA[0], BETA[1], MODEL["T"]).to(dev)
+    weights = list(m.parameters())
+    opt = torch.optim.AdamW(weights, lr=1e-4, weight_decay=1e-4)
+    flat = parallel.FlatGradients(weights, world, overlap=True) if world > 1 else None
+    g = torch.Generator().manual_seed(1 + rank)              # per-rank data
+    x0 = (torch.rand(batch, 3, size, size, generator=g) * 2 - 1).to(dev)
+    labels = (torch.arange(batch) % 2 + 1).to(dev)
+    torch.manual_seed(100 + rank)                            # per-rank t / noise / dropout streams
+    exchanged = 0
+    loss = None
+
+    def step():
+        nonlocal exchanged, loss
+        if flat is not None:
+            flat.zero_()
+        else:
+            opt.zero_grad()
+        loss = tr(x0, labels).sum() / batch ** 2.
+        loss.backward()
+        if flat is not None:
+            exchanged = flat.exchange_mean_()
+        gn = torch.nn.utils.clip_grad_norm_(weights, 1.0)
+        opt.step()
+        return gn
+
+    torch.cuda.reset_peak_memory_stats(dev)
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gn = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    dt = parallel.max_over_ranks((time.perf_counter() - t0) / steps, None if rehearse else dev)
+    fwd = FWD_GFLOP.get(size, FWD_GFLOP[64] * (size / 64) ** 2)
+    res = {"size": size, "batch_per_gpu": batch, "n_gpus": world, "s_per_step": dt, "samples_per_s": world * batch / dt,
+           "fwd_equiv_tflops_per_gpu": 3 * fwd * batch / 1e3 / dt, "loss": float(loss), "grad_norm": float(gn),
+           "all_grads_present": all(p.grad is not None for p in weights),
+           "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 1e9, "gradient_exchange_bytes_per_rank": exchanged,
+           "dropout": dropout, "steps": steps, "warmup": warmup}
+    del opt, tr, m, weights, flat
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline + parity
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(size, batch, dev):
+    """Oracle on the host cores: ONE whole UNet forward at 128x128, B = 1 (the largest size that finishes in seconds;
+    attention is 60 % of its FLOPs against 85 % at 256x256), scaled to one denoising step of the benchmark (2 * batch
+    forwards at `size`) by the algorithmic FLOP ratio.  The same input then goes through the HIP path: `parity`."""
+    from oracle import cpu_path as O
+    threads = _host_threads()
+    m = _model(MODEL, "cpu")
     sd = {k: v.detach() for k, v in m.state_dict().items()}
-    cfg = O.UNetConfig(T=MODEL["T"], num_labels=MODEL["num_labels"], ch=MODEL["ch"], ch_mult=tuple(MODEL["ch_mult"]),
-                       num_res_blocks=MODEL["num_res_blocks"])
+    cfg = _oracle_cfg(MODEL)
     S = 128
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, 3, S, S, generator=g)
+    t, lab = torch.tensor([500]), torch.tensor([1])
     with torch.no_grad():
         O.unet_forward(sd, cfg, torch.randn(1, 3, 32, 32, generator=g), torch.tensor([5]), torch.tensor([1]))  # warm
         t0 = time.perf_counter()
-        O.unet_forward(sd, cfg, x, torch.tensor([500]), torch.tensor([1]))
+        ref = O.unet_forward(sd, cfg, x, t, lab)
         dt = time.perf_counter() - t0
+        md = m.to(dev)
+        eps = md(x.to(dev), t.to(dev), lab.to(dev)).cpu()
+    del md, m
+    err = (eps - ref).abs().max().item()
+    rng = (ref.max() - ref.min()).item()
+    mse = ((eps.double() - ref.double()) ** 2).mean().item()
+    parity = {"what": f"UNet forward (default model, seed-0 init) at {S}x{S}, B=1, t=500, label=1: HIP path vs CPU oracle "
+                      "(oracle/cpu_path.py, pinned to the real reference by tests/golden/unet_default128.npz)",
+              "max_abs": err, "ref_abs_max": ref.abs().max().item(),
+              "psnr_db": float("inf") if mse == 0 else 10.0 * __import__("math").log10(rng * rng / mse),
+              "psnr_note": "on eps with data_range = max - min of the oracle's output", "tolerance_max_abs": 2e-4}
     fwd = FWD_GFLOP[size] if size in FWD_GFLOP else FWD_GFLOP[S] * (size / S) ** 4
     scale = 2 * batch * fwd / FWD_GFLOP[S]
-    return {"value": 1.0 / (dt * scale), "unit": "denoising-steps/s", "cores": threads, "kind": "port",
+    base = {"value": 1.0 / (dt * scale), "unit": "denoising-steps/s", "cores": threads, "kind": "port",
             "sample": f"one UNet forward at {S}x{S}, B=1 on the CPU oracle (blockwise attention) took {dt:.1f} s = "
                       f"{FWD_GFLOP[S] / dt:.0f} GFLOP/s; one step of the benchmark is 2x{batch} forwards at {size}x{size} = "
                       f"{scale:.0f}x its FLOPs (the reference's own materialised-attention formulation cannot run at "
                       "256x256: 137 GB/sample)",
             "measured_s": dt, "torch_threads": threads}
+    return base, parity
 
 
+def config_c1(dev, small=False):
+    """BASELINE config C1 in full on both sides: 64x64, T=50, B=1, w=1.8, default UNet -- the HIP sampler (hipGraph replay)
+    and the CPU oracle (timed in full on the host cores), shared weights / x_T / per-step noise -> the real same-config
+    GPU/CPU ratio and the end-to-end PSNR / SSIM the metric asks for."""
+    from hdiff_amd.DiffusionFreeGuidence.DiffusionCondition import GaussianDiffusionSampler
+    from oracle import cpu_path as O
+    T_, S, w, beta = (4, 32, 1.8, (1e-4, 0.028)) if small else (50, 64, 1.8, (1e-4, 0.028))
+    cfg = dict(MODEL, T=T_) if not small else dict(T=T_, num_labels=10, ch=32, ch_mult=[1, 2], num_res_blocks=1, dropout=0.0)
+    m = _model(cfg, "cpu")
+    with torch.no_grad():
+        m.tail[2].weight.mul_(0.1)       # default init saturates x to +-1 within a few steps (SURVEY 8c); keep x O(1)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    x_T = torch.randn(1, 3, S, S, generator=g)
+    labels = torch.tensor([1])
+    noise = torch.randn(T_, 1, 3, S, S, generator=g)
+    threads = _host_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ref = O.sampler_forward(sd, _oracle_cfg(cfg), beta[0], beta[1], T_, w, x_T, labels, noise)
+        cpu_s = time.perf_counter() - t0
+        md = m.to(dev)
+        samp = GaussianDiffusionSampler(md, beta[0], beta[1], T_, w=w).to(dev)
+        out = samp(x_T.to(dev), labels.to(dev), noise_by_step=noise.to(dev))            # parity run (injected noise)
+        samp(x_T.to(dev), labels.to(dev))                                                 # warm: plan, pack, capture
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        samp(x_T.to(dev), labels.to(dev))                                                 # the reference call, whole
+        torch.cuda.synchronize(dev)
+        gpu_s = time.perf_counter() - t0
+    psnr, ssim = _quality(out, ref)
+    res = {"workload": f"C1: sampling {S}x{S}, T={T_}, B=1, w={w}, beta {beta}; GaussianDiffusionSampler.forward whole "
+                       "(pack + capture + T graph replays + clip)",
+           "gpu_steps_per_s": T_ / gpu_s, "gpu_s": gpu_s, "cpu_steps_per_s": T_ / cpu_s, "cpu_s": cpu_s,
+           "cpu_cores": threads, "cpu_kind": "port (oracle/cpu_path.py, all T steps timed)", "gpu_over_cpu": cpu_s / gpu_s,
+           "parity": {"max_abs": (out.cpu() - ref).abs().max().item(), "psnr_db": psnr, "ssim": ssim,
+                      "unsaturated_fraction": (ref.abs() < 1.0).float().mean().item(),
+                      "note": "shared weights (tail conv scaled by 0.1 so the trajectory does not saturate), x_T and "
+                              "per-step noise; PSNR/SSIM on x*0.5+0.5 at 8-bit range like utils/rotinas.py:922-926"}}
+    del samp, md, m
+    return res
+
+
+def other_configs(dev, small=False):
+    """BASELINE configs C1, C2, C5 (one GPU's share) and C3 on this GPU.  Never part of `value`."""
+    out = {}
+    t_all = time.perf_counter()
+    out["C1"] = config_c1(dev, small)
+    _release()
+    mcfg = MODEL if not small else dict(T=1000, num_labels=10, ch=32, ch_mult=[1, 2], num_res_blocks=1, dropout=0.0)
+    model = _model(mcfg, dev)
+    S2, B2, K2 = (32, 2, 3) if small else (128, 16, 20)
+    dt, mem = time_sampler_steps(model, S2, B2, 200, (1e-4, 0.028), GUIDANCE_W, K2, 2, dev)
+    out["C2"] = {"workload": f"C2: sampling {S2}x{S2}, T=200 schedule, B={B2}, w={GUIDANCE_W}, hipGraph replay, {K2} steps "
+                             "after 2 warm-up steps",
+                 "steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "sample_steps_per_s": B2 / dt,
+                 "whole_step_tflops": None if small else 2 * B2 * FWD_GFLOP[S2] / 1e3 / dt, "plan_bytes": mem}
+    _release()
+    S5, B5 = (64, 2) if small else (512, 8)
+    dt, mem = time_sampler_steps(model, S5, B5, MODEL["T"], BETA, GUIDANCE_W, 1, 1, dev)
+    out["C5"] = {"workload": f"C5 (one GPU's share): sampling {S5}x{S5}, T=1000 schedule, B={B5}/GPU, w={GUIDANCE_W}, hipGraph "
+                             "replay, 1 step after 1 warm-up step",
+                 "steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "sample_steps_per_s": B5 / dt,
+                 "whole_step_tflops": None if small else 2 * B5 * FWD_GFLOP[S5] / 1e3 / dt, "plan_bytes": mem}
+    del model
+    _release()
+    S3, B3 = (32, 2) if small else (256, 64)
+    r = train_steps(S3, B3, 1, 1, 0.15, dev, model_cfg=mcfg)
+    r["workload"] = (f"C3: training {S3}x{S3}, T=1000, B={B3}, dropout 0.15: one optimizer step (forward + hand-written "
+                     "backward + clip_grad_norm_ + AdamW, TrainCondition.py:59-63) after 1 warm-up step")
+    out["C3"] = r
+    _release()
+    out["seconds_spent"] = time.perf_counter() - t_all
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# roofline.traffic: counter values measured by tools/profile_round.sh, valid only for the kernel sources they were taken on
+# ----------------------------------------------------------------------------------------------------------------------
+def source_hash(names):
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(CSRC, n), "rb") as f:
+            h.update(n.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic():
+    """(table, stamp): entries of profiles/roofline_traffic.json whose kernel sources still hash to what they were measured on."""
+    prof = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    try:
+        tab = json.load(open(prof))
+    except Exception:
+        return {}, {"status": "absent"}
+    stamp = tab.get("_stamp") or {}
+    out, status = {}, {}
+    for key, meta in (stamp.get("kernels") or {}).items():
+        try:
+            now = source_hash(meta["sources"])
+        except OSError:
+            now = None
+        fresh = now == meta.get("sha256_16")
+        status[key] = "fresh" if fresh else "STALE (kernel source changed since the counters were collected): not reported"
+        if fresh and key in tab:
+            out[key] = tab[key]
+    return out, {"measured_at_commit": stamp.get("commit"), "measured_utc": stamp.get("utc"),
+                 "collected_by": stamp.get("how"), "kernels": status}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain program: become the launcher.  Nothing above has touched the GPU.
+        from hdiff_amd.parallel import launch_ranks
+        sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to label a {world}-rank run as {a.gpus} GPUs")
     dist = world > 1
     if dist:
         import torch.distributed as td
@@ -116,14 +393,12 @@ def main():
 
     import hdiff_amd
     from hdiff_amd import _capi
-    from hdiff_amd.DiffusionFreeGuidence.ModelCondition import UNet
     from hdiff_amd.DiffusionFreeGuidence.DiffusionCondition import GaussianDiffusionSampler, _SamplerPlan
     lib = hdiff_amd.lib()
 
     S, B, K, Wm = a.size, a.batch, a.steps, a.warmup
     hdiff_amd.set_contraction_mode(a.contract)
-    torch.manual_seed(0)                              # same weights on every rank (replicated model)
-    model = UNet(**MODEL).eval().to(dev)
+    model = _model(MODEL, dev)
     sampler = GaussianDiffusionSampler(model, BETA[0], BETA[1], MODEL["T"], w=GUIDANCE_W).to(dev)
     g = torch.Generator().manual_seed(1234 + rank)    # per-rank data
     x_T = torch.randn(B, 3, S, S, generator=g).to(dev)
@@ -132,14 +407,19 @@ def main():
     with torch.no_grad():
         sp = _SamplerPlan(sampler, B, S, S, dev)
         plan = sp.variant(False, 1234 + rank)
-        sp.x.copy_(x_T)
+        sp.unet.plan.pack_weights()
         sp.unet.labels.copy_(torch.cat([labels, torch.zeros_like(labels)]))
-        sp.step.fill_(MODEL["T"] - 1)
-        sp.nan_flag.zero_()
         stream = torch.cuda.current_stream(dev).cuda_stream
         use_graph = not a.eager
         if use_graph:
             plan.capture()
+
+        def reset():
+            """Every pass starts from the same state: x = x_T at time step T-1 (so the passes run the same time steps and the
+            step counter never leaves the schedule, whatever K is)."""
+            sp.x.copy_(x_T)
+            sp.step.fill_(MODEL["T"] - 1)
+            sp.nan_flag.zero_()
 
         # launches of interest: attention over the full-resolution token set (dominant), the full-resolution 128 -> 128 3x3
         # convolutions, the full-resolution GroupNorm statistics passes
@@ -175,6 +455,7 @@ def main():
                     lib.hdiff_event_record(e1, stream)
                     events[hooked[i]].append((e0, e1))
 
+        reset()
         for _ in range(Wm):
             one_step()
         if dist:
@@ -190,9 +471,13 @@ def main():
         assert int(sp.nan_flag.item()) == 0, "nan in tensor."
         assert int(sp.step.item()) == MODEL["T"] - 1 - (K + Wm)
 
-        # second pass: the same K steps as plain launches with HIP events around the launches of interest
+        # second pass: the same steps (same start state, same time steps) as plain launches with HIP events around the
+        # launches of interest; the warm-up steps are replayed so that the K instrumented steps are the K timed ones
         kernel_pass_s = None
         if not a.no_kernel_pass:
+            reset()
+            for _ in range(Wm):
+                one_step()
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for _ in range(K):
@@ -207,6 +492,7 @@ def main():
             other = "bf16x3" if a.contract == "f32" else "f32"
             hdiff_amd.set_contraction_mode(other)
             use_graph = False                         # a captured graph bakes the contraction mode: plain launches here
+            reset()
             one_step()
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
@@ -237,13 +523,7 @@ def main():
         durations[gname] = vals
 
     if rank == 0:
-        traffic_tab = {}
-        prof = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.isfile(prof):
-            try:
-                traffic_tab = json.load(open(prof))
-            except Exception:
-                traffic_tab = {}
+        traffic_tab, traffic_stamp = load_traffic()
         flops_per_launch = 4.0 * L_full * L_full * Cc * (2 * B)          # QK^T + PV over 8 heads, 2B samples (CFG)
         roof = None
         att_ms = durations.get("attn") or []
@@ -259,6 +539,7 @@ def main():
                               f"heads=8 batch={2 * B}",
                     "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic_tab.get(f"mha_flash_fwd_L{L_full}_B{2 * B}"),
+                    "traffic_stamp": traffic_stamp,
                     "avg_launch_ms": round(avg, 3), "launches_timed": len(att_ms),
                     "algorithmic_flop_per_launch": flops_per_launch,
                     "timed_in": "second pass of the same K steps as plain launches (HIP events on the launch stream)",
@@ -305,8 +586,27 @@ def main():
                        "attention_contract": a.contract, "other_contract_mode": alt},
             "roofline": roof,
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, B)
+    # everything below is outside the timed region and never enters `value`; N = 1 only
+    if rank == 0 and world == 1:
+        del plan, sp, sampler, model
+        _release()
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(S, B, dev)
+            _release()
+        if not a.no_extras:
+            try:
+                out["configs"] = other_configs(dev, small=a.extras_scale == "small")
+                c1 = out["configs"].get("C1")
+                if c1 and "cpu_baseline" in out:
+                    out["cpu_baseline"]["same_config"] = {k: c1[k] for k in ("workload", "gpu_steps_per_s", "cpu_steps_per_s",
+                                                                             "cpu_s", "cpu_cores", "cpu_kind", "gpu_over_cpu")}
+                if c1 and "parity" in out:
+                    out["parity"]["end_to_end_C1"] = c1["parity"]
+            except Exception as e:     # the headline line must survive a failure of an auxiliary leg -- but say so loudly
+                import traceback
+                traceback.print_exc()
+                out["configs"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:
         td.destroy_process_group()

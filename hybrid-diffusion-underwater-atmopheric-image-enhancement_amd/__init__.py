@@ -7,13 +7,20 @@ directory as the importable package ``hdiff_amd``:
     from hdiff_amd.DiffusionFreeGuidence.ModelCondition import UNet
     from hdiff_amd.DiffusionFreeGuidence.DiffusionCondition import GaussianDiffusionSampler, GaussianDiffusionTrainer
 
-or, as a literal drop-in for the reference's imports, put this directory on ``sys.path`` and keep
-``from DiffusionFreeGuidence.DiffusionCondition import ...`` unchanged (INTEGRATION.md).
+or, as a literal drop-in for the reference's own import lines (``MainCondition.py:1``, ``TrainCondition.py:15-17``):
+
+    import hdiff_amd; hdiff_amd.install_dropin()
+    from DiffusionFreeGuidence.TrainCondition import train, eval        # unchanged reference code from here on
+
+(INTEGRATION.md section 1).
 """
+import importlib
+import sys
+
 from . import _capi
 from ._capi import build, lib
 
-__all__ = ["build", "lib", "UNet", "GaussianDiffusionTrainer", "GaussianDiffusionSampler", "extract",
+__all__ = ["build", "lib", "install_dropin", "UNet", "GaussianDiffusionTrainer", "GaussianDiffusionSampler", "extract",
            "set_contraction_mode", "get_contraction_mode"]
 
 _CONTRACT = {"f32": 0, "bf16x3": 1}
@@ -32,6 +39,50 @@ def set_contraction_mode(mode: str) -> None:
 
 def get_contraction_mode() -> str:
     return {v: k for k, v in _CONTRACT.items()}[lib().hdiff_get_contraction_mode()]
+
+
+_DROPIN_MODULES = (
+    # name the reference imports            module of this package that answers it
+    ("DiffusionFreeGuidence", "DiffusionFreeGuidence"),
+    ("DiffusionFreeGuidence.DiffusionCondition", "DiffusionFreeGuidence.DiffusionCondition"),
+    ("DiffusionFreeGuidence.ModelCondition", "DiffusionFreeGuidence.ModelCondition"),
+    ("DiffusionFreeGuidence.TrainCondition", "DiffusionFreeGuidence.TrainCondition"),
+    ("Scheduler", "Scheduler"),                  # TrainCondition.py:17 `from Scheduler import GradualWarmupScheduler`
+    ("MainCondition", "MainCondition"),
+)
+_DROPIN_MODULES_TREE_B = (
+    ("diffusion", "diffusion"),                  # utils/rotinas.py:17-18 `from diffusion.Diffusion import ...`
+    ("diffusion.Diffusion", "diffusion.Diffusion"),
+    ("diffusion.Model", "diffusion.Model"),
+)
+
+
+def install_dropin(second_tree: bool = True, force: bool = False) -> dict:
+    """Make the reference's OWN import statements resolve to this package, without touching the reference's files:
+
+        from DiffusionFreeGuidence.TrainCondition import train, eval                         (MainCondition.py:1)
+        from DiffusionFreeGuidence.DiffusionCondition import GaussianDiffusionSampler, GaussianDiffusionTrainer
+        from DiffusionFreeGuidence.ModelCondition import UNet
+        from Scheduler import GradualWarmupScheduler                                          (TrainCondition.py:15-17)
+        from diffusion.Diffusion import GaussianDiffusionSampler; from diffusion.Model import DynamicUNet   (second tree)
+
+    Every module is imported under its real name (``hdiff_amd.DiffusionFreeGuidence.TrainCondition`` ...: their relative
+    imports into this package are resolved there) and the SAME module object is then registered under the reference's
+    name.  Registering only the package would not do: the import system would re-load ``TrainCondition.py`` from the
+    package's ``__path__`` as a top-level ``DiffusionFreeGuidence.TrainCondition`` and its ``from .. import parallel`` would
+    fail.  Call it before the reference's modules are imported (``sys.modules`` wins over ``sys.path``, so it also works
+    from inside the reference's checkout); a name already imported from somewhere else raises unless ``force``.
+    Returns {reference name: module}."""
+    table = _DROPIN_MODULES + (_DROPIN_MODULES_TREE_B if second_tree else ())
+    mods = {ref: importlib.import_module(f"{__name__}.{own}") for ref, own in table}
+    for ref, mod in mods.items():
+        old = sys.modules.get(ref)
+        if old is not None and old is not mod and not force:
+            raise ImportError(f"install_dropin: '{ref}' is already imported from {getattr(old, '__file__', old)!r}; call "
+                              "install_dropin() before the reference's modules are imported (or pass force=True)")
+    for ref, mod in mods.items():
+        sys.modules[ref] = mod
+    return mods
 
 
 def __getattr__(name):

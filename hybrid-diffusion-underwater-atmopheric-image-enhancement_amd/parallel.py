@@ -16,6 +16,10 @@ DDP with one process per GPU (utils/rotinas.py:572-577, 619).  The hot path shar
 from __future__ import annotations
 
 import os
+import socket
+import subprocess
+import sys
+import time
 from typing import Iterable, List, Sequence, Tuple
 
 import torch
@@ -39,6 +43,53 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
         else:
             dist.init_process_group(backend=backend)
     return rank, local, world
+
+
+def launch_ranks(script: str, argv: Sequence[str], nproc: int, poll_s: float = 0.2) -> int:
+    """Start `nproc` fresh rank processes of `script` on this node, one per GPU, and wait for them; returns the job's exit
+    code (0 only if every rank returned 0).  The counterpart of the reference's `mp.spawn(train, nprocs=world_size)`
+    (utils/rotinas.py:572-577) for programs that are started as plain `python prog.py --gpus N`.
+
+    The caller must NOT have touched the GPU (no HIP call, no `torch.cuda.is_available()`): children are new processes
+    (`subprocess.Popen`, never `os.exec*`) that initialise the device themselves from RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT, exactly the environment `torch.distributed.run` would hand them.  Rank 0 inherits stdout
+    (the one JSON line of a bench goes through untouched); the other ranks' stdout is sent to stderr.  When a rank
+    fails, the remaining ranks -- exactly the PIDs started here -- are terminated so that nobody waits in a collective."""
+    nproc = int(nproc)
+    if nproc < 1:
+        raise ValueError("launch_ranks: nproc must be >= 1")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs: List[subprocess.Popen] = []
+    for r in range(nproc):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script, *argv], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = set(range(nproc))
+    try:
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"launch_ranks: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for q in live:
+                        procs[q].terminate()
+            if live:
+                time.sleep(poll_s)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+    return rc
 
 
 def shard_range(n: int, world: int, rank: int) -> Tuple[int, int]:

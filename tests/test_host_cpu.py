@@ -265,3 +265,111 @@ def test_inline_asm_packed_math_keeps_the_trans_use_wait_state(tmp_path, source,
                 srcs = set().union(*[regs(o) for o in cur.split(None, 1)[1].split(",")[1:]])
                 assert not (regs(prev.split(None, 1)[1].split(",")[0]) & srcs), (prev, cur)
     assert n_pk > 100            # the packed instructions are really there (the check above is not vacuous)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The drop-in for the reference's own entry files (north_star: "so MainCondition.py is a drop-in")
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference's import statements, verbatim: MainCondition.py:1 and DiffusionFreeGuidence/TrainCondition.py:15-17
+REFERENCE_IMPORT_LINES = (
+    "from DiffusionFreeGuidence.TrainCondition import train, eval",
+    "from DiffusionFreeGuidence.DiffusionCondition import GaussianDiffusionSampler, GaussianDiffusionTrainer",
+    "from DiffusionFreeGuidence.ModelCondition import UNet",
+    "from Scheduler import GradualWarmupScheduler",
+    # the second tree's (utils/rotinas.py:17-18)
+    "from diffusion.Diffusion import GaussianDiffusionSampler as SamplerB",
+    "from diffusion.Model import DynamicUNet",
+)
+
+
+def _run_fresh(code: str, cwd: str):
+    return subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, cwd=cwd, timeout=300)
+
+
+def test_install_dropin_serves_the_reference_import_lines(tmp_path):
+    """A fresh interpreter, NOT started in the repo: install_dropin(), then the reference's import statements as they stand."""
+    code = "\n".join([
+        f"import sys; sys.path.insert(0, {ROOT!r})",
+        "import hdiff_amd; mods = hdiff_amd.install_dropin()",
+        *REFERENCE_IMPORT_LINES,
+        "import MainCondition",
+        "assert train.__module__ == 'hdiff_amd.DiffusionFreeGuidence.TrainCondition', train.__module__",
+        "assert UNet is hdiff_amd.UNet and GaussianDiffusionSampler is hdiff_amd.GaussianDiffusionSampler",
+        "assert GradualWarmupScheduler.__module__ == 'hdiff_amd.Scheduler'",
+        "assert DynamicUNet.__module__ == 'hdiff_amd.diffusion.Model'",
+        "assert MainCondition.main.__module__ == 'hdiff_amd.MainCondition'",
+        "import DiffusionFreeGuidence as D; assert D.UNet is UNet and D.train is train",     # `from DiffusionFreeGuidence import *` users
+        "print('OK', len(mods))",
+    ])
+    res = _run_fresh(code, str(tmp_path))
+    assert res.returncode == 0 and "OK 9" in res.stdout, res.stderr[-3000:]
+
+
+def test_install_dropin_refuses_to_shadow_an_imported_reference_module(tmp_path):
+    (tmp_path / "Scheduler.py").write_text("X = 1\n")
+    code = "\n".join([
+        f"import sys; sys.path.insert(0, {ROOT!r})",
+        "import Scheduler",                                  # somebody else's module of that name, imported first
+        "import hdiff_amd",
+        "try:\n    hdiff_amd.install_dropin()\nexcept ImportError as e:\n    print('REFUSED', e)",
+        "assert 'DiffusionFreeGuidence' not in sys.modules",  # nothing half-installed
+        "hdiff_amd.install_dropin(force=True); from Scheduler import GradualWarmupScheduler; print('FORCED')",
+    ])
+    res = _run_fresh(code, str(tmp_path))
+    assert res.returncode == 0 and "REFUSED" in res.stdout and "FORCED" in res.stdout, res.stdout + res.stderr[-3000:]
+
+
+REFERENCE_MAIN = "/root/reference/MainCondition.py"
+
+
+@pytest.mark.skipif(not os.path.isfile(REFERENCE_MAIN), reason="the reference checkout exists in the build container only")
+def test_reference_main_file_itself_runs_against_the_dropin(tmp_path):
+    """The reference's REAL MainCondition.py, unmodified, executed from the reference's own directory (where its
+    `DiffusionFreeGuidence/` package -- which does not even import, SyntaxError at ModelCondition.py:289 -- is first on
+    sys.path): after install_dropin() its line 1 binds this package's train / eval and `main()` hands them the reference's
+    default config.  train is replaced by a recorder (no GPU here); the config it receives must equal the defaults table
+    of this package's MainCondition."""
+    code = "\n".join([
+        f"import sys, json, runpy; sys.path.insert(0, {ROOT!r})",
+        "import hdiff_amd; hdiff_amd.install_dropin()",
+        "import hdiff_amd.DiffusionFreeGuidence.TrainCondition as TC",
+        "seen = []",
+        "TC.train = lambda cfg: seen.append(('train', cfg))",
+        "TC.eval = lambda cfg: seen.append(('eval', cfg))",
+        f"ns = runpy.run_path({REFERENCE_MAIN!r}, run_name='__main__')",
+        "assert len(seen) == 1 and seen[0][0] == 'train', seen",
+        "from hdiff_amd.MainCondition import default_config",
+        "assert seen[0][1] == default_config(), (seen[0][1], default_config())",
+        "ns['main'](dict(default_config(), state='eval')); assert seen[1][0] == 'eval'",
+        "print('OK')",
+    ])
+    res = _run_fresh(code, os.path.dirname(REFERENCE_MAIN))
+    assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-3000:]
+
+
+def test_launch_ranks_relays_rank0_and_propagates_failure(tmp_path):
+    """hdiff_amd.parallel.launch_ranks (what `bench.py --gpus N` becomes when no launcher started it): N fresh processes
+    with the torch.distributed.run environment, rank 0's stdout relayed alone, a failing rank fails the job."""
+    prog = tmp_path / "prog.py"
+    prog.write_text("import os, sys\n"
+                    "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+                    "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                    "print('line from rank', r, 'of', w, sys.argv[1:])\n"
+                    "sys.exit(3 if (len(sys.argv) > 2 and r == 1) else 0)\n")
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import hdiff_amd\n"
+            "from hdiff_amd.parallel import launch_ranks\n"
+            f"sys.exit(launch_ranks({str(prog)!r}, sys.argv[1:], 3))\n")
+    ok = subprocess.run([os.sys.executable, "-c", code, "--x"], capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0, ok.stderr
+    assert ok.stdout.strip().splitlines() == ["line from rank 0 of 3 ['--x']"]          # the other ranks' stdout went to stderr
+    assert "line from rank 2 of 3" in ok.stderr
+    bad = subprocess.run([os.sys.executable, "-c", code, "--x", "--fail"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 3 and "rank 1 exited with 3" in bad.stderr
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """`bench.py --gpus 8` inside a 2-rank job (or the reverse) must not print a mislabelled line."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([os.sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True,
+                         env=env, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr and not res.stdout.strip()
