@@ -77,8 +77,9 @@ class GaussianDiffusionTrainer(nn.Module):
         lib = _capi.lib()
         B = int(x_0.shape[0])
         if t is None:
-            t = torch.randint(self.T, size=(B,), device=x_0.device)
-        t = _timesteps(t, self.T, x_0.device)
+            t = torch.randint(self.T, size=(B,), device=x_0.device)     # in range by construction: no device->host read
+        else:
+            t = _timesteps(t, self.T, x_0.device)                        # a caller's vector is validated like torch.gather would
         if noise is None:
             noise = torch.randn_like(x_0)
         noise = _gpu_input(noise, "noise")

@@ -48,12 +48,15 @@ def _dataset(cfg: Dict):
     if kind == "reference_sets":
         # the reference's own data/ tree (utils/utils.py:309-473): reference images of the named underwater and / or
         # atmospheric sets, label = 0 for underwater, 1 for atmospheric
-        from ..datasets import Atmospheric_Dataset, ReferenceImagesWithDomain, Underwater_Dataset
-        sets = []
+        from ..datasets import (ATMOSPHERIC_DOMAIN, UNDERWATER_DOMAIN, Atmospheric_Dataset, ReferenceImagesWithDomain,
+                                Underwater_Dataset)
+        sets = []                                     # (set, domain id): the id is fixed per kind, whatever else is configured
         if cfg.get("underwater_dataset"):
-            sets.append(Underwater_Dataset(cfg["underwater_dataset"], task="train", root=cfg.get("underwater_root")))
+            sets.append((Underwater_Dataset(cfg["underwater_dataset"], task="train", root=cfg.get("underwater_root")),
+                         UNDERWATER_DOMAIN))
         if cfg.get("atmospheric_dataset"):
-            sets.append(Atmospheric_Dataset(cfg["atmospheric_dataset"], task="train", root=cfg.get("atmospheric_root")))
+            sets.append((Atmospheric_Dataset(cfg["atmospheric_dataset"], task="train", root=cfg.get("atmospheric_root")),
+                         ATMOSPHERIC_DOMAIN))
         if not sets:
             raise ValueError("dataset 'reference_sets' needs underwater_dataset and / or atmospheric_dataset")
         return ReferenceImagesWithDomain(sets, cfg["img_size"])

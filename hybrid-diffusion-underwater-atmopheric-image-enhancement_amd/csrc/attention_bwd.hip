@@ -485,8 +485,13 @@ struct BwdGeom { int nk, nkb_total, per, nsplit; };
 static BwdGeom bwd_geometry(int B, int heads, int L, int D) {
   BwdGeom g;
   g.nk = (L <= 4096 || D >= 48) ? 1 : (D > 16 ? 2 : 4);   // short sequences: 64-key blocks for enough workgroups
+  { // dev knob: a SMALLER key block.  Only the widths the launch dispatches on (1, 2, 4) are accepted -- any other value
+    // would size the geometry for a kernel that is never launched -- and the raggedness rule below applies to the result.
+    static const char* e = getenv("HDIFF_BWD_NK");
+    const int v = e ? atoi(e) : 0;
+    if ((v == 1 || v == 2 || v == 4) && v <= g.nk) g.nk = v;
+  }
   if (L % (64 * g.nk) != 0) g.nk = 1;                      // ragged sequences: the generic (bounds-checked) kernel, 64-key blocks
-  { static const char* e = getenv("HDIFF_BWD_NK"); if (e && atoi(e) > 0 && atoi(e) <= g.nk) g.nk = atoi(e); }   // dev knob
   const int KB = 64 * g.nk;
   g.nkb_total = cdiv(L, KB);
   const int pairs = B * heads;

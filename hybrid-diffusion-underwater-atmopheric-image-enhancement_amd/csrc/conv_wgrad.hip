@@ -271,12 +271,14 @@ int ceil_log2w(int v) {
 
 extern "C" int hdiff_conv2d_wgrad_workspace(const hdiff_conv_wgrad_desc* d, int* nsplit_out, int64_t* floats_out) {
   HDIFF_CHECK_ARG(d && nsplit_out && floats_out, "conv2d_wgrad_workspace: null pointer");
-  if (wgrad1x1_applicable(d)) {
+  const bool specialised = getenv("HDIFF_WGRAD_GENERIC") == nullptr;   // the same dev switch as in hdiff_conv2d_wgrad: the
+                                                                       // A/B run of the generic kernel gets ITS split
+  if (specialised && wgrad1x1_applicable(d)) {
     *nsplit_out = wgrad1x1_nsplit(d);
     *floats_out = (int64_t)*nsplit_out * d->ntaps * d->CinPad * d->CoutPad;
     return HDIFF_OK;
   }
-  if (wgrad3x3_applicable(d)) {
+  if (specialised && wgrad3x3_applicable(d)) {
     *nsplit_out = wgrad3x3_nsplit(d);
     *floats_out = (int64_t)*nsplit_out * d->ntaps * d->CinPad * d->CoutPad;
     return HDIFF_OK;

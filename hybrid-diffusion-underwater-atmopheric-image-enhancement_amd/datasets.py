@@ -133,13 +133,22 @@ class Atmospheric_Dataset(_PairedSet):
         self.dataset_name, self.batch_size = atmospheric_dataset_name, batch_size
 
 
+UNDERWATER_DOMAIN, ATMOSPHERIC_DOMAIN = 0, 1      # fixed class ids: a checkpoint trained on one domain samples with the same label later
+
+
 class ReferenceImagesWithDomain(Dataset):
     """What the class-conditional trainer consumes (TrainCondition.py:27-30,55-56: an image in [-1, 1] and an integer
-    label): the REFERENCE side of the paired sets, label = index of the set in ``sets`` (e.g. 0 = underwater, 1 =
-    atmospheric), images resized to ``img_size``."""
+    label): the REFERENCE side of the paired sets, images resized to ``img_size``.  ``sets`` holds ``(set, domain_id)``
+    pairs; a bare set gets the id of its kind (``Underwater_Dataset`` -> 0, ``Atmospheric_Dataset`` -> 1) -- never its position
+    in the list, so an atmospheric-only run and a two-domain run agree on what label 1 (class 2 after the trainer's + 1) means."""
 
-    def __init__(self, sets: Sequence[_PairedSet], img_size: int):
-        self.items = [(p, li) for li, s in enumerate(sets) for p in s.paths_b]
+    def __init__(self, sets: Sequence, img_size: int):
+        self.items = []
+        for entry in sets:
+            s, dom = entry if isinstance(entry, tuple) else (entry, None)
+            if dom is None:
+                dom = ATMOSPHERIC_DOMAIN if isinstance(s, Atmospheric_Dataset) else UNDERWATER_DOMAIN
+            self.items += [(p, int(dom)) for p in s.paths_b]
         self.img_size = img_size
 
     def __len__(self):

@@ -145,7 +145,7 @@ class FlatGradients:
     """
 
     def __init__(self, params: Sequence[torch.nn.Parameter], world: int | None = None, overlap: bool = False,
-                 bucket_bytes: int = 64 << 20, single_rank_collectives: bool = False):
+                 bucket_bytes: int = 64 << 20, single_rank_collectives: bool = False, skip_unused: bool = True):
         self.params = [p for p in params if p.requires_grad]
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         w = self.world
@@ -180,6 +180,14 @@ class FlatGradients:
         # one rank must give the gradients back bit for bit)
         self.single = bool(single_rank_collectives)
         self.overlap = bool(overlap) and (w > 1 or self.single)
+        # skip_unused (overlap only): a parameter that received no gradient in the FIRST step (an unused module, a frozen
+        # branch) is not waited for from then on -- otherwise it would hold back its bucket and every later one until
+        # exchange_mean_() and the overlap would silently be lost.  The assumption is DDP's static graph: the set of used
+        # parameters does not change; a gradient for such a parameter arriving after its bucket has left raises.
+        self.skip_unused = bool(skip_unused)
+        self._absent: set = set()
+        self._learned = False
+        self._fired: List[bool] = [False] * len(self.params)
         self._pending: List[int] = []
         self._ready: List[bool] = []
         self._work: list = []
@@ -192,7 +200,10 @@ class FlatGradients:
 
     def _arm(self) -> None:
         self._pending = list(self._count)
-        self._ready = [False] * len(self.buckets)
+        for i in self._absent:
+            self._pending[self._owner[i]] -= 1
+        self._fired = [False] * len(self.params)
+        self._ready = [n == 0 for n in self._pending]      # a bucket of unused parameters only: goes out with its neighbours
         self._work = [None] * len(self.buckets)
         self._next = 0
 
@@ -203,7 +214,12 @@ class FlatGradients:
             b = self._owner[i]
             if b < self._next:
                 raise RuntimeError("FlatGradients(overlap=True): a gradient arrived after its bucket had been sent -- one "
-                                   "backward per zero_() / exchange_mean_(); accumulate over several backwards with overlap=False")
+                                   "backward per zero_() / exchange_mean_(); accumulate over several backwards with overlap=False"
+                                   + ("; this parameter got no gradient in the first step and was no longer waited for: "
+                                      "pass skip_unused=False if the set of used parameters changes" if i in self._absent else ""))
+            self._fired[i] = True
+            if i in self._absent:                            # used again, and in time: its bucket simply was not waiting for it
+                return
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._ready[b] = True
@@ -248,6 +264,9 @@ class FlatGradients:
             gathers.append(dist.all_gather_into_tensor(self.flat[lo:hi], self.shards[b], async_op=True))
         for g in gathers:
             g.wait()
+        if self.overlap and self.skip_unused and not self._learned:
+            self._absent = {i for i, f in enumerate(self._fired) if not f}
+            self._learned = True
         self._arm()
         return self.flat.numel() * 4
 

@@ -65,5 +65,12 @@ def test_underwater_and_atmospheric_layouts(tmp_path):
     assert len(both) == 7
     x, lab = both[5]
     assert lab == 1 and tuple(x.shape) == (3, 32, 32) and x.dtype == torch.float32 and -1.0 <= float(x.min()) and float(x.max()) <= 1.0
+    # the domain id belongs to the KIND of set, not to its position: an atmospheric-only run labels its images 1 too, and an
+    # explicit (set, id) pair overrides
+    alone = D.ReferenceImagesWithDomain([D.Atmospheric_Dataset("LoLI", task="train", root=aroot)], img_size=32)
+    assert len(alone) == 3 and {alone[i][1] for i in range(3)} == {D.ATMOSPHERIC_DOMAIN} == {1}
+    assert {both[i][1] for i in range(4)} == {D.UNDERWATER_DOMAIN} == {0}
+    pinned = D.ReferenceImagesWithDomain([(tr, 5)], img_size=32)
+    assert pinned[0][1] == 5
     with pytest.raises(FileNotFoundError):
         D.load_image(str(tmp_path / "missing.png"))

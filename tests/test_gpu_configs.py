@@ -356,3 +356,102 @@ def test_c5_unet_512_cfg_batching():
         assert (mean - (c1 * x - c2 * ((1. + 1.8) * e_c - 1.8 * e_u))).abs().max().item() < 1e-6
     flops = m.plan_for(1, 512, 512, torch.device(DEV)).plan.flops
     assert abs(flops / 83254.1e9 - 1.0) < 0.01, flops
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The configs at their FULL per-GPU batch (BASELINE.json: C3 = batch 64 at 256x256, C5 = batch 8 per GPU at 512x512)
+# ----------------------------------------------------------------------------------------------------------------------
+def test_c3_trainer_step_256_at_batch_64():
+    """One optimizer step of TrainCondition.py:59-63 at BASELINE config C3's real batch (256x256, B = 64, ~130 GB of saved
+    activations): finite, every parameter receives a gradient, and batch entries do not interact -- the per-sample loss
+    planes of samples 0 and 1 equal those of a B = 2 run on the same (x_0, t, noise) (attention / GroupNorm / conv launches
+    index the batch correctly up to B*heads = 512 and B*C = 32 768 slices)."""
+    B = 64
+    m = default_model(0).to(DEV).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0                                          # dropout masks are drawn per launch: not comparable across batch sizes
+    tr = DC.GaussianDiffusionTrainer(m, 1e-4, 0.02, 1000).to(DEV)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(64)
+    x_0 = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(DEV)
+    noise = torch.randn(B, 3, 256, 256, generator=g).to(DEV)
+    t = torch.randint(1000, (B,), generator=g).to(DEV)
+    labels = (torch.arange(B) % 2 + 1).to(DEV)
+    with torch.no_grad():
+        before = {n: p.detach().clone() for n, p in list(m.named_parameters())[:4]}
+    torch.cuda.reset_peak_memory_stats()
+    opt.zero_grad()
+    per_elem = tr(x_0, labels, t=t, noise=noise)                # [B, 3, 256, 256], unreduced (DiffusionCondition.py:45)
+    loss = per_elem.sum() / B ** 2.
+    loss.backward()
+    norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+    opt.step()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 1e9
+    print(f"C3 B=64: loss {loss.item():.4f}, grad norm {norm.item():.4f}, peak memory {peak:.0f} GB")
+    assert torch.isfinite(loss) and torch.isfinite(norm) and norm.item() > 0
+    missing = [n for n, p in m.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()
+               or (p.grad.abs().max().item() == 0 and "cond_embedding.condEmbedding.0" not in n)]
+    assert not missing, missing[:5]
+    assert any(not torch.equal(before[n], p.detach()) for n, p in list(m.named_parameters())[:4])   # AdamW moved the weights
+    first_two = per_elem[:2].detach().clone()
+    del per_elem, loss
+    opt.zero_grad(set_to_none=True)
+    torch.cuda.empty_cache()
+    # the same two samples on their own, with the weights the big step started from
+    m2 = default_model(0).to(DEV).train()
+    for mod in m2.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    tr2 = DC.GaussianDiffusionTrainer(m2, 1e-4, 0.02, 1000).to(DEV)
+    with torch.no_grad():
+        small = tr2(x_0[:2].contiguous(), labels[:2].contiguous(), t=t[:2].contiguous(), noise=noise[:2].contiguous())
+    err = (small - first_two).abs().max().item()
+    print(f"per-sample loss, B=64 run vs B=2 run: max abs diff {err:.2e} (loss values up to {first_two.max().item():.2f})")
+    assert err <= 2e-4 * max(1.0, first_two.abs().max().item())
+
+
+def test_c5_sampler_step_512_at_batch_8():
+    """One captured (hipGraph) denoising step at BASELINE config C5's per-GPU batch: 512x512, B = 8, i.e. a 2B = 16 UNet
+    launch with L = 262 144 tokens.  It must equal eight separate B = 1 steps of the reference loop
+    (DiffusionCondition.py:87-96) on the same x_T / label / injected noise within 2e-4, and replay bit for bit."""
+    B, S, T = 8, 512, 1000
+    m = default_model(0).eval().to(DEV)
+    samp = DC.GaussianDiffusionSampler(m, 1e-4, 0.02, T, w=1.8).to(DEV)
+    g = torch.Generator().manual_seed(8)
+    x_T = torch.randn(B, 3, S, S, generator=g).to(DEV)
+    z = torch.randn(B, 3, S, S, generator=g).to(DEV)
+    labels = (torch.arange(B) % 2 + 1).to(DEV)
+
+    def one_step(x, lab, noise, graph):
+        n = x.shape[0]
+        with torch.no_grad():
+            sp = DC._SamplerPlan(samp, n, S, S, torch.device(DEV))
+            plan = sp.variant(True, 0)
+            sp.unet.plan.pack_weights()
+            outs = []
+            for _ in range(2 if graph else 1):
+                sp.x.copy_(x); sp.noise.copy_(noise)
+                sp.unet.labels.copy_(torch.cat([lab, torch.zeros_like(lab)]))
+                sp.step.fill_(T - 1); sp.nan_flag.zero_()
+                if graph:
+                    plan.capture(); plan.replay()
+                else:
+                    plan.run()
+                torch.cuda.synchronize()
+                assert int(sp.nan_flag.item()) == 0 and int(sp.step.item()) == T - 2
+                outs.append(sp.x.clone())
+        del plan, sp
+        torch.cuda.empty_cache()
+        return outs
+
+    big = one_step(x_T, labels, z, graph=True)
+    assert torch.equal(big[0], big[1])                                              # replay is bitwise repeatable
+    assert torch.isfinite(big[0]).all() and not torch.equal(big[0], x_T)
+    worst = 0.0
+    for i in range(B):
+        one = one_step(x_T[i:i + 1].contiguous(), labels[i:i + 1].contiguous(), z[i:i + 1].contiguous(), graph=False)[0]
+        worst = max(worst, (one - big[0][i:i + 1]).abs().max().item())
+    print(f"C5 B=8 captured step vs eight B=1 steps: max abs diff {worst:.2e}")
+    assert worst < 2e-4

@@ -84,6 +84,18 @@ def _worker(rank, world, port, q):
         sent = fo.exchange_mean_()
         flat_results.append((flat_results[step][0], [p.grad.clone() for p in ps], sent))
     flat_results.append(started_in_backward)
+    # the unused parameter LAST = in the FIRST bucket to leave: in step 0 it holds back every bucket until exchange_mean_;
+    # from step 1 on it is known to be unused (skip_unused) and the buckets leave from the hooks again
+    fu = P.FlatGradients(list(net.parameters()) + [unused], overlap=True, bucket_bytes=64)
+    unused_trace = []
+    for step in range(3):
+        fu.zero_()
+        xb = torch.randn(4, 6, generator=torch.Generator().manual_seed(10 * (step % 2) + rank))
+        net(xb).pow(2).sum().backward()
+        started = fu._next
+        fu.exchange_mean_()
+        unused_trace.append((started, [p.grad.clone() for p in ps]))
+    flat_results.append(unused_trace)
     lo, hi = P.shard_range(11, world, rank)
     t = P.max_over_ranks(1.0 + rank)
     q.put(_plain((rank, w0, local, [p.grad.clone() for p in params], nbytes, (lo, hi), t, P.rank_seed(5, rank), flat_results)))
@@ -111,6 +123,12 @@ def test_two_rank_gradient_exchange_and_sharding():
     assert s0 == (0, 6) and s1 == (6, 11)                              # contiguous, balanced, exhaustive
     assert t0 == t1 == 2.0                                             # max over ranks
     assert seed0 != seed1
+    ut0, ut1 = fr0.pop(), fr1.pop()
+    assert [st for st, _ in ut0] == [st for st, _ in ut1]
+    assert ut0[0][0] == 0 and ut0[1][0] >= 2 and ut0[2][0] >= 2        # step 0 waits for the unused parameter, later steps do not
+    for step, ((_, ga), (_, gb)) in enumerate(zip(ut0, ut1)):
+        for a, b, want in zip(ga, gb, fr0[step % 2][1]):
+            assert torch.equal(a, b) and torch.equal(a, want)              # same means as the plain exchange of the same batch
     started0, started1 = fr0.pop(), fr1.pop()
     assert started0 == started1 and min(started0) >= 1                 # buckets left the hooks during backward, same on both ranks
     assert len(fr0) == 4
