@@ -9,9 +9,39 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The precision contract: the two contraction modes -- fp32-input MFMA ("f32") and the three-piece
+# bf16 split with fp32 accumulation ("bf16x3") -- must BOTH pass the whole golden / oracle / float64 suite of these modules
+# at the SAME tolerances.  Tests that never reach a forward contraction kernel (backward-only kernels, elementwise ops)
+# run once.
+CONTRACT_MODULES = {"test_gpu_model", "test_gpu_configs", "test_gpu_end_to_end", "test_gpu_tree_b"}
+CONTRACT_INDEPENDENT = {"test_c3_attention_backward_full_length", "test_c3_conv_backward_256", "test_small_ops_match_torch"}
+CONTRACT_MODES = ("f32", "bf16x3")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_generate_tests(metafunc):
+    mod = metafunc.module.__name__.split(".")[-1]
+    if mod in CONTRACT_MODULES and metafunc.function.__name__ not in CONTRACT_INDEPENDENT \
+            and "hdiff_contract" in metafunc.fixturenames:
+        metafunc.parametrize("hdiff_contract", CONTRACT_MODES, indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def hdiff_contract(request):
+    """Selects the contraction mode for one test (process-wide switch of libhdiff.so) and restores fp32 afterwards."""
+    mode = getattr(request, "param", None)
+    if mode is None:
+        yield "f32"
+        return
+    import hdiff_amd
+    hdiff_amd.set_contraction_mode(mode)
+    try:
+        yield mode
+    finally:
+        hdiff_amd.set_contraction_mode("f32")
 
 
 @pytest.fixture(scope="session")
