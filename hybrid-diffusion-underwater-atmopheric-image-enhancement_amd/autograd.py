@@ -329,8 +329,13 @@ class _FlashFn(Function):
         Cc, L = C3 // 3, H * W
         o = torch.empty(B, Cc, H, W, device=qkv.device)
         lse = torch.empty(B, NUM_HEADS, L, device=qkv.device)
-        _capi.check(lib.hdiff_mha_flash_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, Cc, NUM_HEADS, L,
-                                            _stream(qkv.device)), "mha_flash_fwd")
+        need = C.c_int64(0)
+        _capi.check(lib.hdiff_mha_flash_fwd_workspace(B, Cc, NUM_HEADS, L, C.byref(need)), "mha_flash_fwd_workspace")
+        # scratch of the pre-split (bf16x3) forward: only allocated when that mode is on; freed when this call returns
+        ws = torch.empty(need.value // 4 + 1, device=qkv.device) if need.value > 0 and lib.hdiff_get_contraction_mode() == 1 else None
+        _capi.check(lib.hdiff_mha_flash_fwd_ws(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, Cc, NUM_HEADS, L,
+                                               None if ws is None else ws.data_ptr(), 0 if ws is None else need.value,
+                                               _stream(qkv.device)), "mha_flash_fwd")
         ctx.save_for_backward(qkv, o, lse)
         return o
 

@@ -555,7 +555,8 @@ void launch_v(const float* qkv, float* o, float* lse2, int B, int C, int heads, 
 }
 
 template <int D>
-int launch_d(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, hipStream_t stream) {
+int launch_d(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, void* ws, int64_t ws_bytes,
+             hipStream_t stream) {
   const float qscale = 1.4426950408889634f / sqrtf((float)D);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   if constexpr (D >= 48) {
@@ -567,7 +568,8 @@ int launch_d(const float* qkv, float* o, float* lse2, int B, int C, int heads, i
     // d_head 32 on the fixed-reference kernel: 134 TFLOP/s against 120 on the running-max kernel (L = 16 384, batch 16)
     if (att_nq_override() > 0) nq = att_nq_override();
     if (nq == 4 && contraction_mode() == HDIFF_CONTRACT_BF16X3 &&
-        launch_mha_fwd_x3(qkv, o, lse2, B, C, heads, L, qscale, stream)) {
+        (launch_mha_fwd_x3p(qkv, o, lse2, B, C, heads, L, qscale, ws, ws_bytes, stream) ||      // pre-split operands (needs the workspace)
+         launch_mha_fwd_x3(qkv, o, lse2, B, C, heads, L, qscale, stream))) {
       // split-bf16 kernel (attention_x3.hip), same fixed-reference protocol: overflow-proof fp32 kernel in check mode behind it
       launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, 1, stream);
     } else if (nq == 4 && L % KT == 0 && att_fast_enabled()) {
@@ -585,24 +587,42 @@ int launch_d(const float* qkv, float* o, float* lse2, int B, int C, int heads, i
 
 }  // namespace
 
-extern "C" int hdiff_mha_flash_fwd(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L,
-                                   hdiff_stream_t stream) {
+static int mha_flash_fwd_any(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, void* ws,
+                             int64_t ws_bytes, hipStream_t s) {
   HDIFF_CHECK_ARG(qkv && o, "mha_flash_fwd: null pointer");
   HDIFF_CHECK_ARG(B > 0 && L > 0 && heads > 0 && C % heads == 0, "mha_flash_fwd: bad sizes B=%d C=%d heads=%d L=%d", B, C,
                   heads, L);
   const int D = C / heads;
-  hipStream_t s = (hipStream_t)stream;
   switch (D) {
-    case 4: return launch_d<4>(qkv, o, lse2, B, C, heads, L, s);
-    case 8: return launch_d<8>(qkv, o, lse2, B, C, heads, L, s);
-    case 12: return launch_d<12>(qkv, o, lse2, B, C, heads, L, s);
-    case 16: return launch_d<16>(qkv, o, lse2, B, C, heads, L, s);
-    case 24: return launch_d<24>(qkv, o, lse2, B, C, heads, L, s);
-    case 32: return launch_d<32>(qkv, o, lse2, B, C, heads, L, s);
-    case 48: return launch_d<48>(qkv, o, lse2, B, C, heads, L, s);
-    case 64: return launch_d<64>(qkv, o, lse2, B, C, heads, L, s);
+    case 4: return launch_d<4>(qkv, o, lse2, B, C, heads, L, ws, ws_bytes, s);
+    case 8: return launch_d<8>(qkv, o, lse2, B, C, heads, L, ws, ws_bytes, s);
+    case 12: return launch_d<12>(qkv, o, lse2, B, C, heads, L, ws, ws_bytes, s);
+    case 16: return launch_d<16>(qkv, o, lse2, B, C, heads, L, ws, ws_bytes, s);
+    case 24: return launch_d<24>(qkv, o, lse2, B, C, heads, L, ws, ws_bytes, s);
+    case 32: return launch_d<32>(qkv, o, lse2, B, C, heads, L, ws, ws_bytes, s);
+    case 48: return launch_d<48>(qkv, o, lse2, B, C, heads, L, ws, ws_bytes, s);
+    case 64: return launch_d<64>(qkv, o, lse2, B, C, heads, L, ws, ws_bytes, s);
     default: break;
   }
   hdiff::set_error("mha_flash_fwd: head dim %d not in {4, 8, 12, 16, 24, 32, 48, 64}", D);
   return HDIFF_ERR_INVALID;
+}
+
+extern "C" int hdiff_mha_flash_fwd(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L,
+                                   hdiff_stream_t stream) {
+  return mha_flash_fwd_any(qkv, o, lse2, B, C, heads, L, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int hdiff_mha_flash_fwd_workspace(int B, int C, int heads, int L, int64_t* bytes_out) {
+  HDIFF_CHECK_ARG(bytes_out, "mha_flash_fwd_workspace: null pointer");
+  HDIFF_CHECK_ARG(B > 0 && L > 0 && heads > 0 && C % heads == 0, "mha_flash_fwd_workspace: bad sizes B=%d C=%d heads=%d L=%d", B,
+                  C, heads, L);
+  *bytes_out = mha_fwd_x3p_workspace(B, C, heads, L);      // a function of the shape only, whatever the contraction mode is now
+  return HDIFF_OK;
+}
+
+extern "C" int hdiff_mha_flash_fwd_ws(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, void* ws,
+                                      int64_t ws_bytes, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(ws_bytes >= 0 && (ws != nullptr || ws_bytes == 0), "mha_flash_fwd_ws: workspace pointer / size mismatch");
+  return mha_flash_fwd_any(qkv, o, lse2, B, C, heads, L, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -1,0 +1,364 @@
+// Flash attention forward on PRE-SPLIT operands: every fp32 value of Q, K, V is written once, by a small streaming kernel,
+// as three bf16 pieces (x = x0 + x1 + x2 exactly, see attention_x3.hip), and the attention kernel contracts the pieces on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Same contract as attention.hip / attention_x3.hip (reference:
+// nn.MultiheadAttention core, ModelCondition.py:189, 204-208); same fixed softmax reference point, overflow poisoning and
+// check pass.
+//
+// Why a second split-bf16 kernel (measured, tools/mfma_bf16_coexec32.hip and profiles/): the bf16 MFMA shares the SIMD's
+// vector issue with the VALU for a FIXED ~8 cycles per instruction, whatever its shape.  The 16x16x32 kernel issues 96 MFMAs
+// of 16 cycles per 64x64 scores of a wave, so half of the matrix time can never hide VALU work; the 32x32x16 shape needs 56
+// MFMAs of 32 cycles for the same scores and leaves 3/4 of the matrix time to the exp / split instructions, which are what
+// bounds this formulation (about 34 VALU cycles per score and lane).  What else moved out of the loop: the K / V / Q splits
+// (done once per tensor here, not once per workgroup: 256 workgroups of a (head, sample) pair used to repeat them).
+//
+//   workspace (bf16), per (sample, head):  Qs[3][L][D] (pre-scaled into the exp2 domain), Ks[3][L][D], Vs[3][D][L]
+//   S^T = K Q^T : M = 32 keys, N = 32 queries, K = 16 of d; the six piece products accumulate in one chain that starts
+//                 from -m (the fixed reference point), so the accumulator IS s - m.
+//   O^T += V^T P: P = exp2(S^T) is split in registers; its accumulator layout (keys 8j + 4h + i on registers, queries on
+//                 lanes) is the B-operand layout of the next MFMA up to a permutation of the contraction slots, which the
+//                 V operand reads follow -- no cross-lane traffic.  d_head 16 fills only half of M = 32, so the two halves
+//                 carry two different V pieces ([v0; v1] with p0 and with p1, [v2; 0] with p0, [v0; 0] with p2: 4 MFMAs
+//                 per 16 keys, the (v1, p1) term comes for free) and are added once at the end; d_head 32 uses 6.
+#include <type_traits>
+
+#include "common.h"
+
+using namespace hdiff;
+
+namespace {
+
+constexpr int KT = 64;
+constexpr int THREADS = 256;
+constexpr float OVERFLOW_LIMIT = 1.2379400e27f;   // 2^90, as in attention.hip
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+}
+__device__ __forceinline__ float top16(float x) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u);
+}
+// (a, b) -> three packed bf16 pairs, a = a0 + a1 + a2 exactly (truncation split; plain VALU only, see attention_x3.hip)
+__device__ __forceinline__ void split3(float a, float b, unsigned& h0, unsigned& h1, unsigned& h2) {
+  h0 = pack_hi16(a, b);
+  const float ra = a - top16(a), rb = b - top16(b);
+  h1 = pack_hi16(ra, rb);
+  const float sa = ra - top16(ra), sb = rb - top16(rb);
+  h2 = pack_hi16(sa, sb);
+}
+
+__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// split-product terms kept (piece of K or V, piece of Q or P): all i + j <= 2, small terms last in the table
+__device__ constexpr int TERM_A[6] = {0, 1, 0, 2, 1, 0};
+__device__ constexpr int TERM_B[6] = {0, 0, 1, 0, 1, 2};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 qkv [B][3C][L]  ->  bf16 pieces in the workspace layout above.  Streaming: reads 4 bytes, writes 6 per element.
+// grid (L / 256, 3 * heads, B), 256 threads.  Q and K: thread = one position, all D channels (reads coalesced over the
+// threads, writes D * 2 contiguous bytes per thread and piece).  V: thread = two neighbouring positions of each channel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(THREADS) void qkv_split3_kernel(const float* __restrict__ qkv, __bf16* __restrict__ ws, int C, int L,
+                                                             float qscale) {
+  const int heads = C / D;
+  const int which = blockIdx.y / heads, head = blockIdx.y - which * heads, b = blockIdx.z;
+  const float* src = qkv + ((size_t)b * 3 * C + (size_t)which * C + (size_t)head * D) * L;
+  __bf16* dst = ws + ((size_t)b * heads + head) * 9 * (size_t)L * D + (size_t)which * 3 * L * D;
+  const size_t piece = (size_t)L * D;
+  if (which < 2) {
+    const int l = blockIdx.x * THREADS + threadIdx.x;
+    if (l >= L) return;
+    const float sc = which == 0 ? qscale : 1.0f;
+    unsigned h[3][D / 2];
+#pragma unroll
+    for (int j = 0; j < D / 2; ++j) {
+      const float a = src[(size_t)(2 * j) * L + l] * sc, c = src[(size_t)(2 * j + 1) * L + l] * sc;
+      split3(a, c, h[0][j], h[1][j], h[2][j]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      u32x4* o = reinterpret_cast<u32x4*>(dst + p * piece + (size_t)l * D);
+#pragma unroll
+      for (int j = 0; j < D / 8; ++j) o[j] = u32x4{h[p][4 * j], h[p][4 * j + 1], h[p][4 * j + 2], h[p][4 * j + 3]};
+    }
+  } else {
+    const int l2 = blockIdx.x * THREADS + threadIdx.x;          // pair index: positions 2*l2, 2*l2 + 1
+    if (2 * l2 >= L) return;
+#pragma unroll 4
+    for (int d = 0; d < D; ++d) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(src + (size_t)d * L + 2 * l2);
+      unsigned h0, h1, h2;
+      split3(v[0], v[1], h0, h1, h2);
+      unsigned* o = reinterpret_cast<unsigned*>(dst + (size_t)d * L) + l2;
+      o[0] = h0;
+      o[piece / 2] = h1;
+      o[piece] = h2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __bf16* __restrict__ ws, float* __restrict__ out,
+                                                                      float* __restrict__ lse2, int C, int L) {
+  static_assert(D == 16 || D == 32, "head dim");
+  constexpr int KS = D / 16;                   // k-steps of the QK^T product
+  constexpr int NPV = (D == 16) ? 4 : 6;       // P.V MFMAs per 16 keys
+  constexpr int KROWB = D * 2 + 16;            // bytes per key of one K piece in LDS (+16: conflict-free ds_read_b128)
+  constexpr int KPART = KT * KROWB;
+  constexpr int VROWB = KT * 2 + 8;            // bytes per d row of one V piece (+8: rows spread over the banks)
+  constexpr int VPART = D * VROWB;
+  constexpr int NKC = 3 * KT * D / 8;          // 16-byte chunks of a K tile (all pieces)
+  constexpr int NVC = 3 * D * 8;               // 16-byte chunks of a V tile
+  constexpr int NLD = (NKC + NVC) / THREADS;   // chunks per thread: 3 (d 16), 6 (d 32)
+  static_assert((NKC + NVC) % THREADS == 0, "staging geometry");
+  constexpr int QB = 256;                      // queries per workgroup: 4 waves x 2 groups of 32
+
+  __shared__ __attribute__((aligned(16))) unsigned char sK[2][3 * KPART];
+  __shared__ __attribute__((aligned(16))) unsigned char sV[2][3 * VPART + VROWB];     // + one row of zeros
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const TileId tile = xcd_tile();
+  const int head = tile.head, b = tile.b;
+  const int heads = gridDim.y;
+  const int qblk0 = tile.x * QB + wave * 64;
+  const size_t piece = (size_t)L * D;
+  const __bf16* qs = ws + ((size_t)b * heads + head) * 9 * piece;
+  const __bf16* ks = qs + 3 * piece;
+  const __bf16* vs = qs + 6 * piece;
+  const int ntiles = L / KT;
+
+  // zero row of both V buffers (read by the upper half of the one-piece V operands at d_head 16)
+  if (tid < 2 * (VROWB / 4)) {
+    const int bufi = tid / (VROWB / 4), w = tid - bufi * (VROWB / 4);
+    *reinterpret_cast<unsigned*>(&sV[bufi][3 * VPART + 4 * w]) = 0u;
+  }
+
+  // Q operands (B of S^T = K Q^T): lane (query l31, half h) holds d = 16 ks + 8 h .. + 7 of each piece
+  u32x4 qop[2][3][KS];
+#pragma unroll
+  for (int G = 0; G < 2; ++G) {
+    const int q = qblk0 + 32 * G + l31;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        qop[G][p][s] = *reinterpret_cast<const u32x4*>(qs + p * piece + (size_t)q * D + 16 * s + 8 * h);
+  }
+
+  // staging: chunk c = i * 256 + tid of the tile's 16-byte chunks (K pieces first, then V pieces)
+  const unsigned char* gsrc[NLD];
+  int lds_off[NLD];
+  int gstep[NLD];
+  bool is_v[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int c = i * THREADS + tid;
+    if (c < NKC) {
+      const int p = c / (KT * D / 8), rem = c - p * (KT * D / 8);
+      const int key = rem / (D / 8), part = rem - key * (D / 8);
+      gsrc[i] = reinterpret_cast<const unsigned char*>(ks + p * piece) + (size_t)rem * 16;
+      lds_off[i] = p * KPART + key * KROWB + part * 16;
+      gstep[i] = KT * D * 2;
+      is_v[i] = false;
+    } else {
+      const int cv = c - NKC;
+      const int p = cv / (D * 8), rem = cv - p * (D * 8);
+      const int d = rem >> 3, seg = rem & 7;
+      gsrc[i] = reinterpret_cast<const unsigned char*>(vs + p * piece + (size_t)d * L) + seg * 16;
+      lds_off[i] = p * VPART + d * VROWB + seg * 16;
+      gstep[i] = KT * 2;
+      is_v[i] = true;
+    }
+  }
+  u32x4 stage[NLD];
+  auto stage_load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) stage[i] = *reinterpret_cast<const u32x4*>(gsrc[i] + (size_t)t * gstep[i]);
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      if (is_v[i]) {
+        unsigned char* dst = &sV[buf][lds_off[i]];
+        *reinterpret_cast<u32x2*>(dst) = u32x2{stage[i][0], stage[i][1]};
+        *reinterpret_cast<u32x2*>(dst + 8) = u32x2{stage[i][2], stage[i][3]};
+      } else {
+        *reinterpret_cast<u32x4*>(&sK[buf][lds_off[i]]) = stage[i];
+      }
+    }
+  };
+
+  // operand addresses inside a buffer
+  const int kaddr = l31 * KROWB + 16 * h;                                  // + piece * KPART + key block * 32 * KROWB + ks * 32
+  int vaddr[3];                                                            // the three V operand kinds of d_head 16 / pieces of d_head 32
+  if (D == 16) {
+    const int d = l31 & 15;
+    const bool up = l31 >= 16;
+    vaddr[0] = (up ? VPART : 0) + d * VROWB + 8 * h;                       // [v0; v1]
+    vaddr[1] = up ? 3 * VPART : 2 * VPART + d * VROWB + 8 * h;             // [v2; 0]
+    vaddr[2] = up ? 3 * VPART : d * VROWB + 8 * h;                         // [v0; 0]
+  } else {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) vaddr[p] = p * VPART + l31 * VROWB + 8 * h;
+  }
+
+  f32x16 O[2];
+  float negm[2];
+  f32x2 l_run[2];
+#pragma unroll
+  for (int G = 0; G < 2; ++G) {
+    negm[G] = 0.f;
+    l_run[G] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[G][r] = 0.f;
+  }
+
+  auto do_block = [&](auto first_tag, int buf, int kb) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const unsigned char* kbuf = sK[buf] + kb * 32 * KROWB + kaddr;
+    const unsigned char* vbuf = sV[buf] + kb * 64;                         // 32 keys = 64 bytes along a V row
+    u32x4 kop[3][KS];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) kop[p][s] = *reinterpret_cast<const u32x4*>(kbuf + p * KPART + 32 * s);
+    // V operands of the two 16-key halves: contraction slot 8 h + 4 jj + i  <->  key 16 ab + 8 jj + 4 h + i
+    u32x4 vop[2][3];
+#pragma unroll
+    for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+      for (int kind = 0; kind < 3; ++kind) {
+        const unsigned char* src = vbuf + vaddr[kind] + 32 * ab;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(src);
+        const u32x2 hi2 = *reinterpret_cast<const u32x2*>(src + 16);
+        vop[ab][kind] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
+      }
+#pragma unroll
+    for (int G = 0; G < 2; ++G) {
+      f32x16 S;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = negm[G];     // the chain starts from -m: the accumulator holds s - m
+#pragma unroll
+      for (int term = 0; term < 6; ++term)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) S = mfma32(kop[TERM_A[term]][s], qop[G][TERM_B[term]][s], S);
+      if (FIRST) {
+        float tm = S[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, S[r]);
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        negm[G] = -tm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] -= tm;
+      }
+      u32x4 pop[2][3];
+      float sum0 = 0.f, sum1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p0 = __builtin_amdgcn_exp2f(S[4 * j]), p1 = __builtin_amdgcn_exp2f(S[4 * j + 1]);
+        const float p2 = __builtin_amdgcn_exp2f(S[4 * j + 2]), p3 = __builtin_amdgcn_exp2f(S[4 * j + 3]);
+        sum0 += p0 + p2;
+        sum1 += p1 + p3;
+        unsigned a0, a1, a2, c0, c1, c2;
+        split3(p0, p1, a0, a1, a2);
+        split3(p2, p3, c0, c1, c2);
+        const int ab = j >> 1, o = (j & 1) * 2;
+        pop[ab][0][o] = a0; pop[ab][1][o] = a1; pop[ab][2][o] = a2;
+        pop[ab][0][o + 1] = c0; pop[ab][1][o + 1] = c1; pop[ab][2][o + 1] = c2;
+      }
+      l_run[G][0] += sum0;
+      l_run[G][1] += sum1;
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab) {
+        if (D == 16) {
+          O[G] = mfma32(vop[ab][2], pop[ab][2], O[G]);     // v0 p2           (small terms first)
+          O[G] = mfma32(vop[ab][1], pop[ab][0], O[G]);     // v2 p0
+          O[G] = mfma32(vop[ab][0], pop[ab][1], O[G]);     // v0 p1, v1 p1
+          O[G] = mfma32(vop[ab][0], pop[ab][0], O[G]);     // v0 p0, v1 p0
+        } else {
+#pragma unroll
+          for (int term = 5; term >= 0; --term) O[G] = mfma32(vop[ab][TERM_A[term]], pop[ab][TERM_B[term]], O[G]);
+        }
+      }
+    }
+  };
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  stage_load(ntiles > 1 ? 1 : 0);
+  do_block(std::true_type{}, 0, 0);
+  do_block(std::false_type{}, 0, 1);
+  stage_store(1);
+  __syncthreads();
+  for (int t = 1; t < ntiles; ++t) {
+    const int buf = t & 1;
+    stage_load((t + 1 < ntiles) ? t + 1 : t);
+    do_block(std::false_type{}, buf, 0);
+    do_block(std::false_type{}, buf, 1);
+    stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* obase = out + ((size_t)b * C + (size_t)head * D) * L;
+#pragma unroll
+  for (int G = 0; G < 2; ++G) {
+    float lt = l_run[G][0] + l_run[G][1];
+    lt += __shfl_xor(lt, 32, 64);
+    const bool bad = !(lt < OVERFLOW_LIMIT);            // overflow (or NaN): hand this query block to the safe kernel
+    const float inv = bad ? __builtin_nanf("") : 1.0f / lt;
+    const int q = qblk0 + 32 * G + l31;
+    if (lse2 != nullptr && h == 0)
+      lse2[((size_t)b * heads + head) * L + q] = bad ? __builtin_nanf("") : __builtin_amdgcn_logf(lt) + negm[G] * -1.0f;
+    // accumulator register r holds row 8 (r / 4) + 4 h + (r % 4) of O^T for query l31
+    if (D == 16) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          obase[(size_t)(8 * jj + 4 * h + i) * L + q] = (O[G][4 * jj + i] + O[G][4 * (jj + 2) + i]) * inv;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) obase[(size_t)(8 * (r >> 2) + 4 * h + (r & 3)) * L + q] = O[G][r] * inv;
+    }
+  }
+}
+
+}  // namespace
+
+namespace hdiff {
+
+// Bytes of workspace the pre-split path needs for this shape; 0 when the shape is not covered (the caller then runs the
+// kernels that split in the loop, or the fp32 ones).
+int64_t mha_fwd_x3p_workspace(int B, int C, int heads, int L) {
+  const int D = C / heads;
+  if ((D != 16 && D != 32) || L % 256 != 0 || L < 512) return 0;
+  return (int64_t)B * 3 * C * L * 6;
+}
+
+bool launch_mha_fwd_x3p(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
+                        int64_t ws_bytes, hipStream_t stream) {
+  const int64_t need = mha_fwd_x3p_workspace(B, C, heads, L);
+  if (need == 0 || ws == nullptr || ws_bytes < need) return false;
+  const int D = C / heads;
+  dim3 sgrid(cdiv(L, 256), 3 * heads, B), grid(L / 256, heads, B);
+  if (D == 16) {
+    hipLaunchKernelGGL((qkv_split3_kernel<16>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);
+    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<16>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
+  } else {
+    hipLaunchKernelGGL((qkv_split3_kernel<32>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);
+    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<32>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
+  }
+  return true;
+}
+
+}  // namespace hdiff

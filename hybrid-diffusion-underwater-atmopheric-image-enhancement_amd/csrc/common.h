@@ -77,6 +77,10 @@ int launch_wgrad1x1(const hdiff_conv_wgrad_desc* d, float* dwp, int nsplit, hipS
 
 int contraction_mode();   // HDIFF_CONTRACT_*
 // attention_x3.hip: returns false when the shape is not covered (caller falls back to the fp32 kernels)
+// attention_x3p.hip: the same contraction on operands split ONCE into a workspace (0 bytes = shape not covered)
+int64_t mha_fwd_x3p_workspace(int B, int C, int heads, int L);
+bool launch_mha_fwd_x3p(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
+                        int64_t ws_bytes, hipStream_t stream);
 bool launch_mha_fwd_x3(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, hipStream_t stream);
 
 }  // namespace hdiff

@@ -24,7 +24,7 @@ int contraction_mode() {
 
 extern "C" {
 
-int hdiff_abi_version(void) { return 3; }   // 3: hdiff_q_sample takes the schedule length, hdiff_mha_flash_bwd a workspace
+int hdiff_abi_version(void) { return 4; }   // 3: hdiff_q_sample takes the schedule length, hdiff_mha_flash_bwd a workspace; 4: hdiff_mha_flash_fwd_ws, hdiff_ddpm_step takes the schedule length
 const char* hdiff_last_error(void) { return hdiff::g_err; }
 
 int hdiff_set_contraction_mode(int mode) {

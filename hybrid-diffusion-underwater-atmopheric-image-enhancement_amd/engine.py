@@ -245,6 +245,13 @@ class Plan:
         if ws is not None:
             self.free(ws)
 
+    def attention_workspace(self, B: int, Cc: int, heads: int, L: int) -> Optional[torch.Tensor]:
+        """Scratch for hdiff_mha_flash_fwd_ws (the operands as bf16 pieces, written and read inside that one call when the
+        contraction mode is bf16x3): sized by the library from the shape alone, so a plan serves both modes."""
+        need = C.c_int64(0)
+        _capi.check(self.lib.hdiff_mha_flash_fwd_workspace(B, Cc, heads, L, C.byref(need)), "mha_flash_fwd_workspace")
+        return self.buf((need.value + 3) // 4) if need.value > 0 else None
+
     def gn_scale_shift(self, x0: torch.Tensor, x1: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
                        B: int, HW: int) -> Tuple[torch.Tensor, torch.Tensor]:
         C0 = int(x0.shape[1])
@@ -320,10 +327,14 @@ def emit_mha(plan: Plan, P: Dict[str, torch.Tensor], p: str, h: torch.Tensor, B:
     qkv = plan.buf(B, 3 * Cc, H, W)
     plan.conv(h, None, pk_in, P[f"{p}.attn.in_proj_bias"], qkv, B=B, H=H, W=W, VH=H, VW=W)
     o = plan.buf(B, Cc, H, W)
-    plan.call("hdiff_mha_flash_fwd", qkv.data_ptr(), o.data_ptr(), None, B, Cc, NUM_HEADS, H * W)
+    ws = plan.attention_workspace(B, Cc, NUM_HEADS, H * W)
+    plan.call("hdiff_mha_flash_fwd_ws", qkv.data_ptr(), o.data_ptr(), None, B, Cc, NUM_HEADS, H * W, _ptr(ws),
+              C.c_int64(0 if ws is None else ws.numel() * 4))
     plan.flops += 4.0 * (H * W) ** 2 * Cc * B
-    plan.keep((qkv, o))
+    plan.keep((qkv, o, ws))
     plan.free(qkv)
+    if ws is not None:
+        plan.free(ws)
     y = plan.buf(B, Cc, H, W)
     plan.conv(o, None, pk_out, P[f"{p}.attn.out_proj.bias"], y, B=B, H=H, W=W, VH=H, VW=W)
     plan.free(o)
@@ -349,7 +360,12 @@ def emit_attn_block(plan: Plan, P: Dict[str, torch.Tensor], p: str, x: torch.Ten
     plan.free(hn)
     o = plan.buf(B, Cc, H, W)
     if Cc <= 64:
-        plan.call("hdiff_mha_flash_fwd", qkv.data_ptr(), o.data_ptr(), None, B, Cc, 1, L)      # one head of width C
+        ws = plan.attention_workspace(B, Cc, 1, L)
+        plan.call("hdiff_mha_flash_fwd_ws", qkv.data_ptr(), o.data_ptr(), None, B, Cc, 1, L, _ptr(ws),     # one head of width C
+                  C.c_int64(0 if ws is None else ws.numel() * 4))
+        plan.keep(ws)
+        if ws is not None:
+            plan.free(ws)
     else:
         plan.call("hdiff_mha_wide_fwd", qkv.data_ptr(), o.data_ptr(), B, Cc, L)
     plan.flops += 4.0 * L * L * Cc * B

@@ -169,6 +169,14 @@ int hdiff_gn_swish_apply(const float* x, const float* scale, const float* shift,
  * ------------------------------------------------------------------------------------------------------------------ */
 int hdiff_mha_flash_fwd(const float* qkv, float* o, float* lse2 /*[B][heads][L] or NULL*/, int B, int C, int heads, int L,
                         hdiff_stream_t stream);
+/* The same call with a caller-provided scratch buffer.  In the bf16x3 contraction mode (hdiff_set_contraction_mode) the
+ * operands are then split ONCE into three bf16 pieces each (a streaming pass into `ws`) and the attention kernel runs on the
+ * pre-split tensors (attention_x3p.hip); without a workspace -- or for a shape the pre-split kernel does not cover, for
+ * which the query returns 0 bytes -- the kernels split inside their loop.  In the fp32 mode `ws` is not touched.  The size
+ * is a function of the shape only (B * 3C * L * 6 bytes when covered: d_head 16 / 32, L a multiple of 256, L >= 512). */
+int hdiff_mha_flash_fwd_workspace(int B, int C, int heads, int L, int64_t* bytes_out);
+int hdiff_mha_flash_fwd_ws(const float* qkv, float* o, float* lse2 /*[B][heads][L] or NULL*/, int B, int C, int heads, int L,
+                           void* ws, int64_t ws_bytes, hdiff_stream_t stream);
 /* Single-head attention with a head wider than 64 channels: softmax(q k^T * C^-1/2) v with d_head = C, the core of the
  * reference's AttnBlock (ModelCondition.py:109-116; dead code there, built for completeness: one workgroup per query row,
  * L + C floats of LDS).  qkv [B][3C][L] rows [q | k | v], o [B][C][L].  Heads of width <= 64: hdiff_mha_flash_fwd, heads = 1. */

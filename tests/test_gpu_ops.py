@@ -204,20 +204,30 @@ def bf16x3_mode():
     _capi.check(lib.hdiff_set_contraction_mode(0))
 
 
-def _flash(lib, qkv, heads, want_lse=False):
+def _flash(lib, qkv, heads, want_lse=False, workspace=False):
+    """workspace=True: hdiff_mha_flash_fwd_ws with the scratch the library asks for (the pre-split kernel in bf16x3 mode)."""
     B, C3, L = qkv.shape
     Cc = C3 // 3
     o = torch.empty(B, Cc, L, device=DEV)
     lse = torch.empty(B, heads, L, device=DEV) if want_lse else None
     d_qkv = qkv.to(DEV)
-    _capi.check(lib.hdiff_mha_flash_fwd(d_qkv.data_ptr(), o.data_ptr(), lse.data_ptr() if want_lse else None, B, Cc, heads, L,
-                                        torch.cuda.current_stream().cuda_stream), "mha")
+    s = torch.cuda.current_stream().cuda_stream
+    if workspace:
+        need = C.c_int64(-1)
+        _capi.check(lib.hdiff_mha_flash_fwd_workspace(B, Cc, heads, L, C.byref(need)), "mha ws query")
+        ws = torch.empty(need.value // 4 + 1, device=DEV) if need.value > 0 else None
+        _capi.check(lib.hdiff_mha_flash_fwd_ws(d_qkv.data_ptr(), o.data_ptr(), lse.data_ptr() if want_lse else None, B, Cc,
+                                               heads, L, None if ws is None else ws.data_ptr(), max(need.value, 0), s), "mha ws")
+    else:
+        _capi.check(lib.hdiff_mha_flash_fwd(d_qkv.data_ptr(), o.data_ptr(), lse.data_ptr() if want_lse else None, B, Cc, heads,
+                                            L, s), "mha")
     torch.cuda.synchronize()
     return o, lse
 
 
+@pytest.mark.parametrize("workspace", [False, True], ids=["split-in-loop", "pre-split"])
 @pytest.mark.parametrize("d,L,B,scale", [(16, 1024, 2, 1.0), (16, 4096, 1, 3.0), (32, 2048, 1, 1.0), (32, 512, 2, 2.0)])
-def test_flash_attention_split_bf16_is_fp32_class(d, L, B, scale, bf16x3_mode):
+def test_flash_attention_split_bf16_is_fp32_class(d, L, B, scale, workspace, bf16x3_mode):
     """HDIFF_CONTRACT_BF16X3: fp32 operands as three bf16 pieces, six products on the bf16 MFMA.  Claim checked here: its
     error against float64 is of the same class as the fp32-MFMA kernel's (not merely inside the tolerance)."""
     lib = bf16x3_mode
@@ -225,7 +235,9 @@ def test_flash_attention_split_bf16_is_fp32_class(d, L, B, scale, bf16x3_mode):
     heads = 8
     qkv = torch.randn(B, 3 * heads * d, L, generator=g) * scale
     ref = attention_core_ref(qkv, heads).double()
-    o_x3, _ = _flash(lib, qkv, heads)
+    o_x3, _ = _flash(lib, qkv, heads, workspace=workspace)
+    if workspace:                                        # the two split-bf16 kernels are different programs
+        assert not torch.equal(o_x3, _flash(lib, qkv, heads)[0]), "the pre-split kernel did not run"
     assert lib.hdiff_get_contraction_mode() == 1
     _capi.check(lib.hdiff_set_contraction_mode(0))
     o_f32, _ = _flash(lib, qkv, heads)
@@ -238,7 +250,8 @@ def test_flash_attention_split_bf16_is_fp32_class(d, L, B, scale, bf16x3_mode):
     assert worst(o_x3) <= 2.0 * worst(o_f32) + 1e-12, (worst(o_x3), worst(o_f32))
 
 
-def test_flash_attention_split_bf16_overflow_falls_back(bf16x3_mode):
+@pytest.mark.parametrize("workspace", [False, True], ids=["split-in-loop", "pre-split"])
+def test_flash_attention_split_bf16_overflow_falls_back(workspace, bf16x3_mode):
     """Same fixed-reference protocol as the fp32 fast kernel: spiked keys / queries overflow exp2 on purpose; the poisoned
     query blocks are recomputed by the overflow-proof kernel."""
     lib = bf16x3_mode
@@ -249,7 +262,7 @@ def test_flash_attention_split_bf16_overflow_falls_back(bf16x3_mode):
     qkv[0, Cc + 2 * d:Cc + 3 * d, 700] *= 90.0
     qkv[1, Cc + 5 * d:Cc + 6 * d, 1999] *= 150.0
     qkv[1, 0 * d:1 * d, 300:364] *= 40.0
-    o, lse = _flash(lib, qkv, heads, want_lse=True)
+    o, lse = _flash(lib, qkv, heads, want_lse=True, workspace=workspace)
     assert torch.isfinite(o).all() and torch.isfinite(lse).all()
     close(o, attention_core_ref(qkv, heads), rel=3e-5, abs_=3e-6, what="split-bf16 overflow fallback")
     q, k, _ = [z.reshape(B, heads, d, L).transpose(2, 3).double() for z in qkv.split(Cc, dim=1)]

@@ -1,13 +1,17 @@
-"""Dev tool: launch the dominant attention kernel a few times at the bench shape (for rocprofv3 --pmc passes)."""
-import os, sys
+"""Dev tool: launch the dominant attention kernel a few times at the bench shape (for rocprofv3 --pmc passes).
+argv: [batch] ; the contraction mode comes from HDIFF_CONTRACT (bf16x3: the pre-split kernel, with its workspace)."""
+import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch, hdiff_amd
 lib = hdiff_amd.lib()
 B, Cc, L = int(sys.argv[1]) if len(sys.argv) > 1 else 16, 128, 65536
 qkv = torch.randn(B, 3 * Cc, L, device="cuda")
 o = torch.empty(B, Cc, L, device="cuda")
+need = C.c_int64(0)
+lib.hdiff_mha_flash_fwd_workspace(B, Cc, 8, L, C.byref(need))
+ws = torch.empty(need.value // 4 + 1, device="cuda") if need.value > 0 else None
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
-    lib.hdiff_mha_flash_fwd(qkv.data_ptr(), o.data_ptr(), None, B, Cc, 8, L, s)
+    lib.hdiff_mha_flash_fwd_ws(qkv.data_ptr(), o.data_ptr(), None, B, Cc, 8, L, None if ws is None else ws.data_ptr(), need.value, s)
 torch.cuda.synchronize()
 print("done")

@@ -84,7 +84,60 @@ void sweep(int w) {
   run<32, 13, KIND>(w); run<16, 13, KIND>(w);
 }
 
-int main() {
+template <int NV>
+__global__ __launch_bounds__(256) void valu_only(float* out, int iters, float seed) {      // the split+exp mix alone
+  float x[8];
+  unsigned u[8];
+  for (int i = 0; i < 8; ++i) { x[i] = seed * (i + 1) + threadIdx.x; u[i] = i; }
+  unsigned msk = 0xffff0000u, sel = 0x07060302u;
+  asm volatile("" : "+s"(msk), "+s"(sel));
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int r = (m * NV + i) & 7;
+        const int j = i % 13;
+        const int kind = (j == 12 || j == 5) ? 1 : (j == 4 || j == 9 || j == 11) ? 12 : ((j & 1) ? 11 : 10);
+        if (kind == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(x[r]));
+        if (kind == 10) asm volatile("v_and_b32 %0, %1, %2" : "=v"(u[r]) : "s"(msk), "v"(x[r]));
+        if (kind == 11) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[r]) : "v"(u[(r + 7) & 7]));
+        if (kind == 12) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(u[r]) : "v"(x[r]), "v"(x[(r + 1) & 7]), "s"(sel));
+      }
+  }
+  float s = 0;
+  for (int i = 0; i < 8; ++i) s += x[i] + (float)u[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+void run_valu(int w) {
+  float* out;
+  int blocks = 256 * w;
+  (void)hipMalloc(&out, blocks * 256 * 4);
+  int iters = 20000;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  valu_only<13><<<blocks, 256>>>(out, 100, 0.3f);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  valu_only<13><<<blocks, 256>>>(out, iters, 0.3f);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  printf("waves/SIMD=%d  VALU only, 13 split+exp per unit: %6.1f SIMD cycles per wave-unit = %.2f per instruction\n", w,
+         ms * 1e-3 * 2.4e9 / iters / 8 / w, ms * 1e-3 * 2.4e9 / iters / 8 / w / 13);
+  (void)hipFree(out);
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) {        // more waves per SIMD: does the VALU side get cheaper?
+    for (int w = 1; w <= 4; ++w) {
+      run_valu(w);
+      run<32, 0, 3>(w); run<32, 9, 3>(w); run<16, 9, 3>(w); run<32, 13, 3>(w); run<16, 13, 3>(w);
+    }
+    return 0;
+  }
   for (int w = 1; w <= 2; ++w) { sweep<0>(w); sweep<2>(w); sweep<3>(w); }
   return 0;
 }
