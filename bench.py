@@ -65,8 +65,9 @@ def parse(argv=None):
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--contract", choices=["f32", "bf16x3"], default="f32",
-                    help="attention contractions: fp32-input MFMA (default) or the fp32-class three-piece bf16 split")
+    ap.add_argument("--contract", choices=["f32", "bf16x3"], default="bf16x3",
+                    help="attention / 3x3-conv contractions: the fp32-class three-piece bf16 split on the bf16 MFMA (the library's "
+                         "default) or the fp32-input MFMA; the other one is run once beside the headline (`other_contract_mode`)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed in `value`) run in the other contraction mode")
     ap.add_argument("--eager", action="store_true", help="time plain launches instead of the hipGraph replay")
     ap.add_argument("--graph", action="store_true", help="(default; kept for old command lines)")
@@ -427,7 +428,7 @@ def main():
         Cc = MODEL["ch"] * MODEL["ch_mult"][0]
         groups = {"attn": [], "conv3x3": [], "gn_stats": []}
         for i, (name, _, args) in enumerate(plan.ops):
-            if name == "hdiff_mha_flash_fwd" and args[6] == L_full:
+            if name in ("hdiff_mha_flash_fwd", "hdiff_mha_flash_fwd_ws") and args[6] == L_full:
                 groups["attn"].append(i)
             elif name == "hdiff_conv2d_fwd":
                 d = args[0]._obj
@@ -503,8 +504,9 @@ def main():
             hdiff_amd.set_contraction_mode(a.contract)
             assert int(sp.nan_flag.item()) == 0, "nan in tensor."
             alt = {"contract": other, "ms_per_step": dt_alt * 1e3, "denoising_steps_per_s": 1.0 / dt_alt,
-                   "note": "same workload with the attention contractions in the other mode; bf16x3 = every fp32 operand as "
-                           "three bf16 pieces, six products on the bf16 MFMA, fp32 accumulate (fp32-class error, "
+                   "note": "same workload with the attention / 3x3-conv contractions in the other mode (plain launches); "
+                           "f32 = fp32-input MFMA (exact k-ordered fma chain); bf16x3 = every fp32 operand as three bf16 "
+                           "pieces, six products on the bf16 MFMA, fp32 accumulate (fp32-class error, "
                            "tests/test_gpu_ops.py::test_flash_attention_split_bf16_is_fp32_class)"}
 
     if dist:
@@ -533,29 +535,34 @@ def main():
             if a.contract == "f32":
                 kname, peak = "mha_flash_fwd_fast_kernel<16,4>", PEAK_F32_MFMA_TFLOPS
             else:   # six bf16 products per fp32 product: the scheme's fp32-equivalent ceiling is the bf16 dense peak / 6
-                kname, peak = "mha_flash_fwd_x3_kernel<16,4> (3xbf16 split, peak = bf16 dense peak / 6)", PEAK_BF16_MFMA_TFLOPS / 6
+                kname, peak = ("split-bf16 flash kernel (attention_x3.hip / attention_x3p.hip: every fp32 product as six bf16 "
+                               "products, fp32 accumulate; peak = bf16 dense MFMA peak / 6)"), PEAK_BF16_MFMA_TFLOPS / 6
             roof = {"bound": "mfma",
                     "kernel": f"hdiff_mha_flash_fwd = {kname} + overflow-check pass, L={L_full} d_head=16 "
                               f"heads=8 batch={2 * B}",
                     "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic_tab.get(f"mha_flash_fwd_L{L_full}_B{2 * B}"),
+                    "frac": round(ach / peak, 4),
+                    "traffic": traffic_tab.get(f"mha_flash_fwd_L{L_full}_B{2 * B}" + ("" if a.contract == "f32" else "_bf16x3")),
                     "traffic_stamp": traffic_stamp,
                     "avg_launch_ms": round(avg, 3), "launches_timed": len(att_ms),
                     "algorithmic_flop_per_launch": flops_per_launch,
                     "timed_in": "second pass of the same K steps as plain launches (HIP events on the launch stream)",
                     "secondary": []}
             conv_ms = durations.get("conv3x3") or []
-            if conv_ms and a.contract == "f32":
+            if conv_ms:
                 avg = sum(conv_ms) / len(conv_ms)
                 fl = 2.0 * 9 * Cc * Cc * L_full * (2 * B)
                 ach = fl / (avg * 1e-3) / 1e12
+                cpeak = PEAK_F32_MFMA_TFLOPS if a.contract == "f32" else PEAK_BF16_MFMA_TFLOPS / 6
+                ckern = ("conv_igemm_kernel (fp32-input MFMA)" if a.contract == "f32" else
+                         "conv3x3_x3_kernel (six bf16 products per fp32 product: peak = bf16 dense MFMA peak / 6)")
                 roof["secondary"].append({
-                    "bound": "mfma", "kernel": f"hdiff_conv2d_fwd = conv_igemm_kernel 3x3 {Cc}->{Cc} at {S}x{S}, batch {2 * B} "
+                    "bound": "mfma", "kernel": f"hdiff_conv2d_fwd = {ckern} 3x3 {Cc}->{Cc} at {S}x{S}, batch {2 * B} "
                                                "(GroupNorm-Swish prologue, bias/vector/residual epilogue)",
-                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_ms": round(avg, 3),
+                    "achieved": round(ach, 2), "peak": round(cpeak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / cpeak, 4), "avg_launch_ms": round(avg, 3),
                     "launches_timed": len(conv_ms), "algorithmic_flop_per_launch": fl,
-                    "traffic": traffic_tab.get(f"conv3x3_{Cc}_{S}_B{2 * B}")})
+                    "traffic": traffic_tab.get(f"conv3x3_{Cc}_{S}_B{2 * B}") if a.contract == "f32" else None})
             gn_ms = durations.get("gn_stats") or []
             if gn_ms:
                 avg = sum(gn_ms) / len(gn_ms)
@@ -573,7 +580,8 @@ def main():
             "metric": "denoising-steps/sec (256x256, T=1000)" if S == 256 else f"denoising-steps/sec ({S}x{S}, T=1000)",
             "value": world * K / elapsed, "unit": "denoising-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.contract == "f32" else "f32 (attention products as 3xbf16 split, fp32 accumulate)",
+            "dtype": "f32" if a.contract == "f32" else "f32 (tensors and accumulation fp32; attention and 3x3-conv products as "
+                     "3xbf16 pieces on the bf16 MFMA, fp32-class error: golden suite green at the fp32 tolerances)",
             "data": "synthetic",
             "config": {"workload": f"CFG-DDPM sampling, {S}x{S}, T=1000 linear schedule (1e-4..0.02), w={GUIDANCE_W}, "
                                    f"batch {B}/GPU (2x{B} UNet forwards per step), default UNet ch=128 ch_mult=[1,2,2,2] "

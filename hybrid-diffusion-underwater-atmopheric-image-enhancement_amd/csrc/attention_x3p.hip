@@ -19,6 +19,8 @@
 //                 V operand reads follow -- no cross-lane traffic.  d_head 16 fills only half of M = 32, so the two halves
 //                 carry two different V pieces ([v0; v1] with p0 and with p1, [v2; 0] with p0, [v0; 0] with p2: 4 MFMAs
 //                 per 16 keys, the (v1, p1) term comes for free) and are added once at the end; d_head 32 uses 6.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -350,6 +352,13 @@ bool launch_mha_fwd_x3p(const float* qkv, float* o, float* lse2, int B, int C, i
   const int64_t need = mha_fwd_x3p_workspace(B, C, heads, L);
   if (need == 0 || ws == nullptr || ws_bytes < need) return false;
   const int D = C / heads;
+  {
+    // dev knob: HDIFF_X3P=0 never, =16 / =32 only that head width, =1 every covered shape.  Unset: d_head 32 only -- at
+    // d_head 16 the kernel that splits in its loop is still the faster one (162 vs 178 TFLOP/s-equivalent, L = 65 536)
+    static const char* e = getenv("HDIFF_X3P");
+    const int sel = e ? atoi(e) : 32;
+    if (sel != D && sel != 1) return false;
+  }
   dim3 sgrid(cdiv(L, 256), 3 * heads, B), grid(L / 256, heads, B);
   if (D == 16) {
     hipLaunchKernelGGL((qkv_split3_kernel<16>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);

@@ -15,8 +15,10 @@ void set_error(const char* fmt, ...) {
 static int g_contract = -1;
 int contraction_mode() {
   if (g_contract < 0) {
+    // Default: the three-piece bf16 split (fp32-class error, pinned by the whole golden suite at the fp32 tolerances:
+    // tests/conftest.py runs it in both modes).  HDIFF_CONTRACT=f32 selects the fp32-input MFMA kernels.
     const char* e = getenv("HDIFF_CONTRACT");
-    g_contract = (e && strcmp(e, "bf16x3") == 0) ? HDIFF_CONTRACT_BF16X3 : HDIFF_CONTRACT_F32;
+    g_contract = (e && strcmp(e, "f32") == 0) ? HDIFF_CONTRACT_F32 : HDIFF_CONTRACT_BF16X3;
   }
   return g_contract;
 }

@@ -12,9 +12,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # The precision contract: the two contraction modes -- fp32-input MFMA ("f32") and the three-piece
 # bf16 split with fp32 accumulation ("bf16x3") -- must BOTH pass the whole golden / oracle / float64 suite of these modules
 # at the SAME tolerances.  Tests that never reach a forward contraction kernel (backward-only kernels, elementwise ops)
-# run once.
-CONTRACT_MODULES = {"test_gpu_model", "test_gpu_configs", "test_gpu_end_to_end", "test_gpu_tree_b"}
-CONTRACT_INDEPENDENT = {"test_c3_attention_backward_full_length", "test_c3_conv_backward_256", "test_small_ops_match_torch"}
+# run once, and so do the tests that pick a mode themselves (the `bf16x3_mode` fixture of test_gpu_ops.py).  The library's
+# default is bf16x3 (HDIFF_CONTRACT=f32 for the other); every fixture restores the mode it found.
+CONTRACT_MODULES = {"test_gpu_model", "test_gpu_configs", "test_gpu_end_to_end", "test_gpu_tree_b", "test_gpu_ops",
+                    "test_gpu_fullsize", "test_gpu_backward"}
+CONTRACT_INDEPENDENT = {"test_c3_attention_backward_full_length", "test_c3_conv_backward_256", "test_small_ops_match_torch",
+                        "test_linear_rows_and_gather", "test_linear_and_embedding_backward", "test_downsample_and_tconv_backward",
+                        "test_fused_conv_backward", "test_ddpm_step_bit_exact_and_nan_flag", "test_q_sample_bit_exact_and_clip",
+                        "test_randn_moments_and_determinism", "test_groupnorm_scale_shift", "test_conv1x1_direct_gemm_path",
+                        "test_conv1x1_and_5x5_stride2"}
 CONTRACT_MODES = ("f32", "bf16x3")
 
 
@@ -25,7 +31,7 @@ def pytest_configure(config):
 def pytest_generate_tests(metafunc):
     mod = metafunc.module.__name__.split(".")[-1]
     if mod in CONTRACT_MODULES and metafunc.function.__name__ not in CONTRACT_INDEPENDENT \
-            and "hdiff_contract" in metafunc.fixturenames:
+            and "hdiff_contract" in metafunc.fixturenames and "bf16x3_mode" not in metafunc.fixturenames:
         metafunc.parametrize("hdiff_contract", CONTRACT_MODES, indirect=True)
 
 
@@ -37,11 +43,12 @@ def hdiff_contract(request):
         yield "f32"
         return
     import hdiff_amd
+    before = hdiff_amd.get_contraction_mode()
     hdiff_amd.set_contraction_mode(mode)
     try:
         yield mode
     finally:
-        hdiff_amd.set_contraction_mode("f32")
+        hdiff_amd.set_contraction_mode(before)
 
 
 @pytest.fixture(scope="session")

@@ -51,6 +51,7 @@ def test_c1_sampling_64x64_T50_matches_cpu_path():
     m = m.to(DEV)
     samp = DC.GaussianDiffusionSampler(m, beta[0], beta[1], T_, w=w).to(DEV)
     lib = hdiff_amd.lib()
+    before = hdiff_amd.get_contraction_mode()
     try:
         for mode in ("f32", "bf16x3"):
             hdiff_amd.set_contraction_mode(mode)
@@ -62,7 +63,7 @@ def test_c1_sampling_64x64_T50_matches_cpu_path():
             print(f"C1 {mode}: worst pre-clip trajectory error {worst:.2e}, PSNR {psnr:.1f} dB, SSIM {ssim:.6f}")
             assert worst < 5e-3 and psnr >= 40.0 and ssim >= 0.99, (mode, worst, psnr, ssim)
     finally:
-        hdiff_amd.set_contraction_mode("f32")
+        hdiff_amd.set_contraction_mode(before)
 
 
 def test_tree_b_ddim_64x64_matches_cpu_path():

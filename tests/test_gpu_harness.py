@@ -58,15 +58,16 @@ def test_bench_json_contract_small():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "configs"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"].startswith("f32") and d["data"] == "synthetic"
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["launches_timed"] == 2 * 2 and r["avg_launch_ms"] > 0
     assert "kernels" in r["traffic_stamp"]
+    assert d["config"]["attention_contract"] == "bf16x3" and "3xbf16" in d["dtype"]        # the library's default mode
     alt = d["config"]["other_contract_mode"]
-    assert alt["contract"] == "bf16x3" and alt["ms_per_step"] > 0
+    assert alt["contract"] == "f32" and alt["ms_per_step"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["same_config"]["cpu_steps_per_s"] > 0
     par = d["parity"]

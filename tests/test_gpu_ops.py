@@ -199,9 +199,10 @@ def test_flash_attention_fixed_reference_overflow_falls_back(d):
 @pytest.fixture
 def bf16x3_mode():
     lib = _capi.lib()
+    before = lib.hdiff_get_contraction_mode()
     _capi.check(lib.hdiff_set_contraction_mode(1))
     yield lib
-    _capi.check(lib.hdiff_set_contraction_mode(0))
+    _capi.check(lib.hdiff_set_contraction_mode(before))
 
 
 def _flash(lib, qkv, heads, want_lse=False, workspace=False):
