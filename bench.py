@@ -136,10 +136,7 @@ def time_sampler_steps(model, size, batch, T, beta, w, steps, warmup, dev, seed=
         sp = _SamplerPlan(sampler, batch, size, size, dev)
         plan = sp.variant(False, seed)
         sp.unet.plan.pack_weights()
-        sp.x.copy_(x_T)
-        sp.unet.labels.copy_(torch.cat([labels, torch.zeros_like(labels)]))
-        sp.step.fill_(T - 1)
-        sp.nan_flag.zero_()
+        sp.reset(x_T, labels)
         if graph:
             plan.capture()
         run = plan.replay if graph else plan.run
@@ -409,7 +406,6 @@ def main():
         sp = _SamplerPlan(sampler, B, S, S, dev)
         plan = sp.variant(False, 1234 + rank)
         sp.unet.plan.pack_weights()
-        sp.unet.labels.copy_(torch.cat([labels, torch.zeros_like(labels)]))
         stream = torch.cuda.current_stream(dev).cuda_stream
         use_graph = not a.eager
         if use_graph:
@@ -418,9 +414,7 @@ def main():
         def reset():
             """Every pass starts from the same state: x = x_T at time step T-1 (so the passes run the same time steps and the
             step counter never leaves the schedule, whatever K is)."""
-            sp.x.copy_(x_T)
-            sp.step.fill_(MODEL["T"] - 1)
-            sp.nan_flag.zero_()
+            sp.reset(x_T, labels)
 
         # launches of interest: attention over the full-resolution token set (dominant), the full-resolution 128 -> 128 3x3
         # convolutions, the full-resolution GroupNorm statistics passes

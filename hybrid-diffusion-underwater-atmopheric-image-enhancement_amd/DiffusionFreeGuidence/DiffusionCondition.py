@@ -100,7 +100,7 @@ class GaussianDiffusionTrainer(nn.Module):
 
 
 class _SamplerPlan:
-    """One captured denoising step for a fixed (B, H, W): fill t -> duplicate x -> 2B UNet -> fused DDPM update."""
+    """One captured denoising step for a fixed (B, H, W): 2B UNet -> fused DDPM update (which also prepares the next step)."""
 
     def __init__(self, sampler: "GaussianDiffusionSampler", B: int, H: int, W: int, device):
         model = sampler.model
@@ -112,6 +112,7 @@ class _SamplerPlan:
         self.noise = torch.empty(B, 3, H, W, device=dev)
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.done = torch.zeros(1, dtype=torch.int32, device=dev)       # finished-workgroup counter of the fused update
         var = torch.cat([sampler.posterior_var[1:2], sampler.betas[1:]])                 # reference :74
         self.c1 = sampler.coeff1.float().contiguous()                                     # extract(): f64 -> f32
         self.c2 = sampler.coeff2.float().contiguous()
@@ -122,20 +123,41 @@ class _SamplerPlan:
         self._sampler = sampler
 
     def _build(self, inject_noise: bool) -> E.Plan:
+        """One denoising step = the 2B UNet launches + ONE fused update kernel.  The update also writes x_next into both
+        halves of the UNet's input, decrements the device-resident step and refills the time vector (hdiff_ddpm_step_loop),
+        so nothing else has to run between two replays; `reset()` puts the loop state at its start."""
         up, B, n = self.unet, self.B, self.n
         p = E.Plan(self.x.device)
-        xin = up.x
-        p.call("hdiff_fill_t", up.t.data_ptr(), self.step.data_ptr(), 2 * B)
-        p.call("hdiff_axpby", C.c_float(1.0), self.x.data_ptr(), C.c_float(0.0), None, xin.data_ptr(), n)
-        p.call("hdiff_axpby", C.c_float(1.0), self.x.data_ptr(), C.c_float(0.0), None, xin.data_ptr() + 4 * n, n)
         p.ops.extend(up.plan.ops)
         eps = up.out
-        p.call("hdiff_ddpm_step", self.x.data_ptr(), eps.data_ptr(), eps.data_ptr() + 4 * n,
-               self.noise.data_ptr() if inject_noise else None, self.x.data_ptr(), self.c1.data_ptr(), self.c2.data_ptr(),
-               self.sigma.data_ptr(), self.step.data_ptr(), C.c_double(float(self._sampler.w)), C.c_uint64(self.seed),
-               self.nan_flag.data_ptr(), n)
-        p.call("hdiff_step_decrement", self.step.data_ptr())
+        d = _capi.DdpmLoopDesc()
+        d.x, d.eps_c, d.eps_u = self.x.data_ptr(), eps.data_ptr(), eps.data_ptr() + 4 * n
+        d.noise = self.noise.data_ptr() if inject_noise else None
+        d.x_next = self.x.data_ptr()
+        d.coeff1, d.coeff2, d.sigma = self.c1.data_ptr(), self.c2.data_ptr(), self.sigma.data_ptr()
+        d.step_ptr, d.T = self.step.data_ptr(), int(self._sampler.T)
+        d.w, d.seed = float(self._sampler.w), self.seed
+        d.nan_flag, d.n = self.nan_flag.data_ptr(), n
+        d.x_dup0, d.x_dup1 = up.x.data_ptr(), up.x.data_ptr() + 4 * n
+        d.t_next, d.t_count = up.t.data_ptr(), 2 * B
+        d.done_counter = self.done.data_ptr()
+        p.keep(d)
+        p.call("hdiff_ddpm_step_loop", C.byref(d))
         return p
+
+    def reset(self, x_T: torch.Tensor, labels: torch.Tensor, step: Optional[int] = None) -> None:
+        """Loop state at its start: x = x_T (also in both halves of the UNet input), labels = [labels; 0] (reference :76-77),
+        the time vector and the device-resident step at T - 1 (or `step`), flags cleared."""
+        T = int(self._sampler.T)
+        step = T - 1 if step is None else int(step)
+        self.x.copy_(x_T)
+        self.unet.x[:self.B].copy_(x_T)
+        self.unet.x[self.B:].copy_(x_T)
+        self.unet.labels.copy_(torch.cat([labels, torch.zeros_like(labels)], dim=0))
+        self.unet.t.fill_(step)
+        self.step.fill_(step)
+        self.nan_flag.zero_()
+        self.done.zero_()
 
     def variant(self, inject_noise: bool, seed: int) -> E.Plan:
         # the guidance weight is a launch argument of the fused update: the reference reads self.w on every step (:78), so
@@ -234,10 +256,7 @@ class GaussianDiffusionSampler(nn.Module):
         inject = noise_by_step is not None
         seed = 0 if inject else int(torch.empty((), dtype=torch.int64).random_().item())
         plan = sp.variant(inject, seed)
-        sp.x.copy_(x_T)
-        sp.unet.labels.copy_(torch.cat([labels, torch.zeros_like(labels)], dim=0))
-        sp.step.fill_(self.T - 1)
-        sp.nan_flag.zero_()
+        sp.reset(x_T, labels)
         graphed = self.use_graph and trajectory is None
         if graphed:
             plan.capture()

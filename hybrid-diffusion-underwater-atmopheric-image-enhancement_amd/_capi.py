@@ -17,6 +17,17 @@ MAX_TAPS = 25
 _lib = None
 
 
+class DdpmLoopDesc(C.Structure):
+    """hdiff_ddpm_loop_desc (include/hdiff.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("eps_c", C.c_void_p), ("eps_u", C.c_void_p), ("noise", C.c_void_p), ("x_next", C.c_void_p),
+        ("coeff1", C.c_void_p), ("coeff2", C.c_void_p), ("sigma", C.c_void_p), ("step_ptr", C.c_void_p), ("T", C.c_int),
+        ("w", C.c_double), ("seed", C.c_uint64), ("nan_flag", C.c_void_p), ("n", C.c_int64),
+        ("x_dup0", C.c_void_p), ("x_dup1", C.c_void_p), ("t_next", C.c_void_p), ("t_count", C.c_int),
+        ("done_counter", C.c_void_p),
+    ]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ("x0", C.c_void_p), ("x1", C.c_void_p), ("C0", C.c_int), ("C1", C.c_int),
@@ -89,11 +100,13 @@ _PROTOS = {
                                  C.c_int, C.c_void_p]),
     "hdiff_sq_err": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hdiff_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_double, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hdiff_ddpm_step_loop": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hdiff_fill_t": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "hdiff_step_decrement": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "hdiff_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "hdiff_fill_from_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "hdiff_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
+                                  C.c_void_p]),
+    "hdiff_fill_from_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hdiff_resize_nearest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hdiff_avgpool_global": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hdiff_concat2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),

@@ -29,6 +29,9 @@ using namespace hdiff;
 
 namespace {
 
+#ifndef X3P_VALU_PER_UNIT
+#define X3P_VALU_PER_UNIT 112      // vector instructions of one unit's exp / split stream (spread over its MFMAs)
+#endif
 constexpr int KT = 64;
 constexpr int THREADS = 256;
 constexpr float OVERFLOW_LIMIT = 1.2379400e27f;   // 2^90, as in attention.hip
@@ -107,7 +110,9 @@ __global__ __launch_bounds__(THREADS) void qkv_split3_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int D>
+// PIPE: the software-pipelined main loop (d_head 16; at d_head 32 its register set does not fit two waves per SIMD and the
+// straight per-block order below is used, which already matches no-waste M = 32 tiles).
+template <int D, bool PIPE>
 __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __bf16* __restrict__ ws, float* __restrict__ out,
                                                                       float* __restrict__ lse2, int C, int L) {
   static_assert(D == 16 || D == 32, "head dim");
@@ -123,8 +128,9 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
   static_assert((NKC + NVC) % THREADS == 0, "staging geometry");
   constexpr int QB = 256;                      // queries per workgroup: 4 waves x 2 groups of 32
 
-  __shared__ __attribute__((aligned(16))) unsigned char sK[2][3 * KPART];
-  __shared__ __attribute__((aligned(16))) unsigned char sV[2][3 * VPART + VROWB];     // + one row of zeros
+  constexpr int VBASE = 3 * KPART;                                         // one buffer = K pieces, V pieces, one row of zeros
+  constexpr int BUFB = (VBASE + 3 * VPART + VROWB + 15) / 16 * 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][BUFB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
   // zero row of both V buffers (read by the upper half of the one-piece V operands at d_head 16)
   if (tid < 2 * (VROWB / 4)) {
     const int bufi = tid / (VROWB / 4), w = tid - bufi * (VROWB / 4);
-    *reinterpret_cast<unsigned*>(&sV[bufi][3 * VPART + 4 * w]) = 0u;
+    *reinterpret_cast<unsigned*>(&smem[bufi][VBASE + 3 * VPART + 4 * w]) = 0u;
   }
 
   // Q operands (B of S^T = K Q^T): lane (query l31, half h) holds d = 16 ks + 8 h .. + 7 of each piece
@@ -160,7 +166,6 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
   const unsigned char* gsrc[NLD];
   int lds_off[NLD];
   int gstep[NLD];
-  bool is_v[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int c = i * THREADS + tid;
@@ -170,15 +175,13 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
       gsrc[i] = reinterpret_cast<const unsigned char*>(ks + p * piece) + (size_t)rem * 16;
       lds_off[i] = p * KPART + key * KROWB + part * 16;
       gstep[i] = KT * D * 2;
-      is_v[i] = false;
     } else {
       const int cv = c - NKC;
       const int p = cv / (D * 8), rem = cv - p * (D * 8);
       const int d = rem >> 3, seg = rem & 7;
       gsrc[i] = reinterpret_cast<const unsigned char*>(vs + p * piece + (size_t)d * L) + seg * 16;
-      lds_off[i] = p * VPART + d * VROWB + seg * 16;
+      lds_off[i] = VBASE + p * VPART + d * VROWB + seg * 16;
       gstep[i] = KT * 2;
-      is_v[i] = true;
     }
   }
   u32x4 stage[NLD];
@@ -186,129 +189,221 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
 #pragma unroll
     for (int i = 0; i < NLD; ++i) stage[i] = *reinterpret_cast<const u32x4*>(gsrc[i] + (size_t)t * gstep[i]);
   };
+  // two 8-byte stores per chunk for K and V alike (V rows are 8-byte aligned): no per-thread branch, so a whole tile of
+  // the main loop stays ONE basic block and the scheduler can keep every unit's vector work beside its MFMAs
   auto stage_store = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      if (is_v[i]) {
-        unsigned char* dst = &sV[buf][lds_off[i]];
-        *reinterpret_cast<u32x2*>(dst) = u32x2{stage[i][0], stage[i][1]};
-        *reinterpret_cast<u32x2*>(dst + 8) = u32x2{stage[i][2], stage[i][3]};
-      } else {
-        *reinterpret_cast<u32x4*>(&sK[buf][lds_off[i]]) = stage[i];
-      }
+      unsigned char* dst = &smem[buf][lds_off[i]];
+      *reinterpret_cast<u32x2*>(dst) = u32x2{stage[i][0], stage[i][1]};
+      *reinterpret_cast<u32x2*>(dst + 8) = u32x2{stage[i][2], stage[i][3]};
     }
   };
 
   // operand addresses inside a buffer
   const int kaddr = l31 * KROWB + 16 * h;                                  // + piece * KPART + key block * 32 * KROWB + ks * 32
-  int vaddr[3];                                                            // the three V operand kinds of d_head 16 / pieces of d_head 32
-  if (D == 16) {
+  constexpr int NVK = (D == 16) ? 2 : 3;                                   // V operand kinds (d_head 16) / pieces (d_head 32)
+  int vaddr[NVK];
+  if constexpr (D == 16) {
     const int d = l31 & 15;
     const bool up = l31 >= 16;
     vaddr[0] = (up ? VPART : 0) + d * VROWB + 8 * h;                       // [v0; v1]
     vaddr[1] = up ? 3 * VPART : 2 * VPART + d * VROWB + 8 * h;             // [v2; 0]
-    vaddr[2] = up ? 3 * VPART : d * VROWB + 8 * h;                         // [v0; 0]
   } else {
 #pragma unroll
     for (int p = 0; p < 3; ++p) vaddr[p] = p * VPART + l31 * VROWB + 8 * h;
   }
 
-  f32x16 O[2];
-  float negm[2];
+  // negm16: the softmax reference point, negated and splat over an accumulator tuple = the C operand that starts every
+  // QK^T chain.  ONE value per lane serves both of its queries (group 0 and group 1): the larger of their two first-block
+  // maxima.  Any reference works as long as exp2 neither overflows nor flushes the whole row; both accidents end in a
+  // NaN output and the check pass (attention.hip) recomputes that query block.
+  f32x16 O[2], negm16;
   f32x2 l_run[2];
 #pragma unroll
   for (int G = 0; G < 2; ++G) {
-    negm[G] = 0.f;
     l_run[G] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[G][r] = 0.f;
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm16[r] = 0.f;
 
-  auto do_block = [&](auto first_tag, int buf, int kb) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    const unsigned char* kbuf = sK[buf] + kb * 32 * KROWB + kaddr;
-    const unsigned char* vbuf = sV[buf] + kb * 64;                         // 32 keys = 64 bytes along a V row
-    u32x4 kop[3][KS];
+  auto load_k = [&](int buf, int kb, u32x4 (&kop)[3][KS]) {
+    const unsigned char* kbuf = smem[buf] + kb * 32 * KROWB + kaddr;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int s = 0; s < KS; ++s) kop[p][s] = *reinterpret_cast<const u32x4*>(kbuf + p * KPART + 32 * s);
-    // V operands of the two 16-key halves: contraction slot 8 h + 4 jj + i  <->  key 16 ab + 8 jj + 4 h + i
-    u32x4 vop[2][3];
+  };
+  // V operands of the two 16-key halves of a 32-key block: contraction slot 8 h + 4 jj + i  <->  key 16 ab + 8 jj + 4 h + i
+  auto load_v = [&](int buf, int kb, u32x4 (&vop)[2][NVK]) {
+    const unsigned char* vbuf = smem[buf] + VBASE + kb * 64;               // 32 keys = 64 bytes along a V row
 #pragma unroll
     for (int ab = 0; ab < 2; ++ab)
 #pragma unroll
-      for (int kind = 0; kind < 3; ++kind) {
+      for (int kind = 0; kind < NVK; ++kind) {
         const unsigned char* src = vbuf + vaddr[kind] + 32 * ab;
         const u32x2 lo = *reinterpret_cast<const u32x2*>(src);
         const u32x2 hi2 = *reinterpret_cast<const u32x2*>(src + 16);
         vop[ab][kind] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
       }
+  };
+  auto qk = [&](const u32x4 (&kop)[3][KS], int G, f32x16 c) {
+    f32x16 S = c;                                  // the chain starts from -m: the accumulator holds s - m
 #pragma unroll
-    for (int G = 0; G < 2; ++G) {
-      f32x16 S;
+    for (int term = 0; term < 6; ++term)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S[r] = negm[G];     // the chain starts from -m: the accumulator holds s - m
+      for (int s = 0; s < KS; ++s) S = mfma32(kop[TERM_A[term]][s], qop[G][TERM_B[term]][s], S);
+    return S;
+  };
+  auto softmax_split = [&](const f32x16& S, int G, u32x4 (&pop)[2][3]) {
+    float sum0 = 0.f, sum1 = 0.f;
 #pragma unroll
-      for (int term = 0; term < 6; ++term)
+    for (int j = 0; j < 4; ++j) {
+      const float p0 = __builtin_amdgcn_exp2f(S[4 * j]), p1 = __builtin_amdgcn_exp2f(S[4 * j + 1]);
+      const float p2 = __builtin_amdgcn_exp2f(S[4 * j + 2]), p3 = __builtin_amdgcn_exp2f(S[4 * j + 3]);
+      sum0 += p0 + p2;
+      sum1 += p1 + p3;
+      unsigned a0, a1, a2, c0, c1, c2;
+      split3(p0, p1, a0, a1, a2);
+      split3(p2, p3, c0, c1, c2);
+      const int ab = j >> 1, o = (j & 1) * 2;
+      pop[ab][0][o] = a0; pop[ab][1][o] = a1; pop[ab][2][o] = a2;
+      pop[ab][0][o + 1] = c0; pop[ab][1][o + 1] = c1; pop[ab][2][o + 1] = c2;
+    }
+    l_run[G][0] += sum0;
+    l_run[G][1] += sum1;
+  };
+  auto pv = [&](const u32x4 (&vop)[2][NVK], const u32x4 (&pop)[2][3], int G) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) S = mfma32(kop[TERM_A[term]][s], qop[G][TERM_B[term]][s], S);
-      if (FIRST) {
-        float tm = S[0];
+    for (int ab = 0; ab < 2; ++ab) {
+      if constexpr (D == 16) {
+        O[G] = mfma32(vop[ab][0], pop[ab][2], O[G]);     // v0 p2 (and v1 p2: a term beyond the six, for free)   small terms first
+        O[G] = mfma32(vop[ab][1], pop[ab][0], O[G]);     // v2 p0
+        O[G] = mfma32(vop[ab][0], pop[ab][1], O[G]);     // v0 p1, v1 p1
+        O[G] = mfma32(vop[ab][0], pop[ab][0], O[G]);     // v0 p0, v1 p0
+      } else {
 #pragma unroll
-        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, S[r]);
-        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-        negm[G] = -tm;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] -= tm;
-      }
-      u32x4 pop[2][3];
-      float sum0 = 0.f, sum1 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float p0 = __builtin_amdgcn_exp2f(S[4 * j]), p1 = __builtin_amdgcn_exp2f(S[4 * j + 1]);
-        const float p2 = __builtin_amdgcn_exp2f(S[4 * j + 2]), p3 = __builtin_amdgcn_exp2f(S[4 * j + 3]);
-        sum0 += p0 + p2;
-        sum1 += p1 + p3;
-        unsigned a0, a1, a2, c0, c1, c2;
-        split3(p0, p1, a0, a1, a2);
-        split3(p2, p3, c0, c1, c2);
-        const int ab = j >> 1, o = (j & 1) * 2;
-        pop[ab][0][o] = a0; pop[ab][1][o] = a1; pop[ab][2][o] = a2;
-        pop[ab][0][o + 1] = c0; pop[ab][1][o + 1] = c1; pop[ab][2][o + 1] = c2;
-      }
-      l_run[G][0] += sum0;
-      l_run[G][1] += sum1;
-#pragma unroll
-      for (int ab = 0; ab < 2; ++ab) {
-        if (D == 16) {
-          O[G] = mfma32(vop[ab][2], pop[ab][2], O[G]);     // v0 p2           (small terms first)
-          O[G] = mfma32(vop[ab][1], pop[ab][0], O[G]);     // v2 p0
-          O[G] = mfma32(vop[ab][0], pop[ab][1], O[G]);     // v0 p1, v1 p1
-          O[G] = mfma32(vop[ab][0], pop[ab][0], O[G]);     // v0 p0, v1 p0
-        } else {
-#pragma unroll
-          for (int term = 5; term >= 0; --term) O[G] = mfma32(vop[ab][TERM_A[term]], pop[ab][TERM_B[term]], O[G]);
-        }
+        for (int term = 5; term >= 0; --term) O[G] = mfma32(vop[ab][TERM_A[term]], pop[ab][TERM_B[term]], O[G]);
       }
     }
   };
+  // One MFMA, then its share of the unit's VALU instructions: the bf16 MFMA hides only a few vector instructions each
+  // (tools/mfma_bf16_coexec32.hip), so the matrix work has to be spread evenly through the exp / split stream.
+  auto interleave = [&](auto nm_tag) {
+    constexpr int nm = decltype(nm_tag)::value;
+#pragma unroll
+    for (int i = 0; i < nm; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, X3P_VALU_PER_UNIT / nm, 0);
+    }
+  };
+  constexpr int NM_QK = 6 * KS, NM_PV = 2 * NPV;
 
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
-  stage_load(ntiles > 1 ? 1 : 0);
-  do_block(std::true_type{}, 0, 0);
-  do_block(std::false_type{}, 0, 1);
-  stage_store(1);
-  __syncthreads();
-  for (int t = 1; t < ntiles; ++t) {
-    const int buf = t & 1;
-    stage_load((t + 1 < ntiles) ? t + 1 : t);
-    do_block(std::false_type{}, buf, 0);
-    do_block(std::false_type{}, buf, 1);
-    stage_store(buf ^ 1);
+  if constexpr (PIPE) {
+    // ---- prologue: tiles 0 and 1 into the two buffers; the reference point m of each query group from its first 32 keys
+    stage_load(0);
+    stage_store(0);
+    stage_load(ntiles > 1 ? 1 : 0);
+    stage_store(1);
     __syncthreads();
+    u32x4 Ka[3][KS], Kb[3][KS], Va[2][NVK], Vb[2][NVK], popA[2][3], popB[2][3];
+    f32x16 Sa, Sb;
+    load_k(0, 0, Ka);
+    {
+      Sa = qk(Ka, 0, negm16);                       // C = 0 here
+      Sb = qk(Ka, 1, negm16);
+      float tm = fmaxf(Sa[0], Sb[0]);
+  #pragma unroll
+      for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(Sa[r], Sb[r]));
+      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+  #pragma unroll
+      for (int r = 0; r < 16; ++r) { negm16[r] = -tm; Sa[r] -= tm; }
+    }
+
+    // ---- steady state.  Unit u = (tile, 32-key block kb, query group G); in unit u the matrix core runs QK^T of unit u + 1
+    // and P.V of unit u - 1 while the VALU turns S(u) into split P(u).  Register names alternate (Sa/Sb, popA/popB, Ka/Kb,
+    // Va/Vb) so that nothing is copied from one unit to the next.  ONE barrier per tile: after unit 2 every wave has read
+    // this tile's K / V from LDS, so unit 3 may overwrite the buffer with tile t + 2 (loaded during this tile) -- and read
+    // tile t + 1's first K block from the other buffer, written two barriers ago.
+    auto tile_body = [&](auto first_tag, int t) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      const int buf = t & 1;
+      stage_load(min(t + 2, ntiles - 1));
+      // unit 0: (kb 0, G 0)
+      load_v(buf, 0, Va);
+      Sb = qk(Ka, 1, negm16);
+      if (!FIRST) pv(Vb, popB, 1);
+      softmax_split(Sa, 0, popA);
+      interleave(std::integral_constant<int, NM_QK + (FIRST ? 0 : NM_PV)>{});
+      // unit 1: (kb 0, G 1)
+      load_k(buf, 1, Kb);
+      Sa = qk(Kb, 0, negm16);
+      pv(Va, popA, 0);
+      softmax_split(Sb, 1, popB);
+      interleave(std::integral_constant<int, NM_QK + NM_PV>{});
+      // unit 2: (kb 1, G 0)
+      load_v(buf, 1, Vb);
+      Sb = qk(Kb, 1, negm16);
+      pv(Va, popB, 1);
+      softmax_split(Sa, 0, popA);
+      interleave(std::integral_constant<int, NM_QK + NM_PV>{});
+      __syncthreads();
+      asm volatile("" : "+v"(Sb));     // keep unit 3's exp / split stream behind the barrier, beside unit 3's MFMAs
+      // unit 3: (kb 1, G 1)
+      load_k(buf ^ 1, 0, Ka);
+      Sa = qk(Ka, 0, negm16);
+      pv(Vb, popA, 0);
+      softmax_split(Sb, 1, popB);
+      interleave(std::integral_constant<int, NM_QK + NM_PV>{});
+      stage_store(buf);
+    };
+    tile_body(std::true_type{}, 0);
+    for (int t = 1; t < ntiles; ++t) tile_body(std::false_type{}, t);
+    pv(Vb, popB, 1);
+  } else {
+    // ---- straight order: per 32-key block and query group  QK^T -> exp / split -> P.V  (the two waves of a SIMD overlap
+    // each other's phases)
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    stage_load(ntiles > 1 ? 1 : 0);
+    {
+      u32x4 K0[3][KS];
+      load_k(0, 0, K0);
+      const f32x16 s0 = qk(K0, 0, negm16), s1 = qk(K0, 1, negm16);       // C = 0 here
+      float tm = fmaxf(s0[0], s1[0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(s0[r], s1[r]));
+      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm16[r] = -tm;
+    }
+    auto block = [&](int buf, int kb) {
+      u32x4 kop[3][KS], vop[2][NVK];
+      load_k(buf, kb, kop);
+      load_v(buf, kb, vop);
+#pragma unroll
+      for (int G = 0; G < 2; ++G) {
+        const f32x16 S = qk(kop, G, negm16);
+        u32x4 pop[2][3];
+        softmax_split(S, G, pop);
+        pv(vop, pop, G);
+      }
+    };
+    block(0, 0);
+    block(0, 1);
+    stage_store(1);
+    __syncthreads();
+    for (int t = 1; t < ntiles; ++t) {
+      const int buf = t & 1;
+      stage_load((t + 1 < ntiles) ? t + 1 : t);
+      block(buf, 0);
+      block(buf, 1);
+      stage_store(buf ^ 1);
+      __syncthreads();
+    }
   }
 
   float* obase = out + ((size_t)b * C + (size_t)head * D) * L;
@@ -320,7 +415,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
     const float inv = bad ? __builtin_nanf("") : 1.0f / lt;
     const int q = qblk0 + 32 * G + l31;
     if (lse2 != nullptr && h == 0)
-      lse2[((size_t)b * heads + head) * L + q] = bad ? __builtin_nanf("") : __builtin_amdgcn_logf(lt) + negm[G] * -1.0f;
+      lse2[((size_t)b * heads + head) * L + q] = bad ? __builtin_nanf("") : __builtin_amdgcn_logf(lt) - negm16[0];
     // accumulator register r holds row 8 (r / 4) + 4 h + (r % 4) of O^T for query l31
     if (D == 16) {
 #pragma unroll
@@ -362,10 +457,10 @@ bool launch_mha_fwd_x3p(const float* qkv, float* o, float* lse2, int B, int C, i
   dim3 sgrid(cdiv(L, 256), 3 * heads, B), grid(L / 256, heads, B);
   if (D == 16) {
     hipLaunchKernelGGL((qkv_split3_kernel<16>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);
-    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<16>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
+    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<16, true>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
   } else {
     hipLaunchKernelGGL((qkv_split3_kernel<32>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);
-    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<32>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
+    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<32, false>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
   }
   return true;
 }

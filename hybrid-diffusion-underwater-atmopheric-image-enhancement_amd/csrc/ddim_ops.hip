@@ -21,9 +21,10 @@ inline int grid_for(int64_t n, int per_thread = 1) {
 // tab[k] = {sqrt(1 - at), sqrt(at), sqrt(at_next), c2} of DDIM step k, formed on the host with the reference's fp32 ops.
 // y and y_next may be the same buffer (the sampler updates in place): neither is __restrict__.
 __global__ void ddim_step_kernel(const float* y, const float* __restrict__ eps, float* y_next,
-                                 const float* __restrict__ tab, const int32_t* __restrict__ step_ptr,
+                                 const float* __restrict__ tab, const int32_t* __restrict__ step_ptr, int nsteps,
                                  int32_t* __restrict__ nan_flag, int64_t n) {
-  const int k = *step_ptr;
+  int k = *step_ptr;
+  k = k < 0 ? 0 : (k >= nsteps ? nsteps - 1 : k);          // never index outside the table, whatever the counter holds
   const float s1m = tab[4 * k + 0], sa = tab[4 * k + 1], san = tab[4 * k + 2], c2 = tab[4 * k + 3];
   bool bad = false;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -38,9 +39,12 @@ __global__ void ddim_step_kernel(const float* y, const float* __restrict__ eps, 
   }
 }
 
-__global__ void fill_from_table_kernel(int64_t* dst, const int32_t* __restrict__ table, const int32_t* __restrict__ idx, int n) {
+__global__ void fill_from_table_kernel(int64_t* dst, const int32_t* __restrict__ table, const int32_t* __restrict__ idx,
+                                       int table_len, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = (int64_t)table[*idx];
+  int k = *idx;
+  k = k < 0 ? 0 : (k >= table_len ? table_len - 1 : k);
+  if (i < n) dst[i] = (int64_t)table[k];
 }
 
 // F.interpolate(mode="nearest"): src = min(floor(dst * (float)in / out), in - 1), computed in float like ATen does
@@ -82,20 +86,22 @@ __global__ void avgpool_global_kernel(const float* __restrict__ x, float* __rest
 
 extern "C" {
 
-int hdiff_ddim_step(const float* y, const float* eps, float* y_next, const float* tab, const int32_t* step_ptr,
+int hdiff_ddim_step(const float* y, const float* eps, float* y_next, const float* tab, const int32_t* step_ptr, int nsteps,
                     int32_t* nan_flag, int64_t n, hdiff_stream_t stream) {
-  HDIFF_CHECK_ARG(y && eps && y_next && tab && step_ptr && nan_flag && n > 0, "ddim_step: bad arguments");
+  HDIFF_CHECK_ARG(y && eps && y_next && tab && step_ptr && nan_flag && n > 0 && nsteps > 0, "ddim_step: bad arguments");
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, y, eps, y_next, tab, step_ptr,
-                     nan_flag, n);
+                     nsteps, nan_flag, n);
   HDIFF_CHECK_LAUNCH("ddim_step_kernel");
   return HDIFF_OK;
 }
 
-int hdiff_fill_from_table(int64_t* dst, const int32_t* table, const int32_t* idx, int n, hdiff_stream_t stream) {
-  HDIFF_CHECK_ARG(dst && table && idx && n > 0, "fill_from_table: bad arguments");
+int hdiff_fill_from_table(int64_t* dst, const int32_t* table, const int32_t* idx, int table_len, int n,
+                          hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(dst && table && idx && n > 0 && table_len > 0, "fill_from_table: bad arguments");
   (void)hipGetLastError();
-  hipLaunchKernelGGL(fill_from_table_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, dst, table, idx, n);
+  hipLaunchKernelGGL(fill_from_table_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, dst, table, idx, table_len,
+                     n);
   HDIFF_CHECK_LAUNCH("fill_from_table_kernel");
   return HDIFF_OK;
 }

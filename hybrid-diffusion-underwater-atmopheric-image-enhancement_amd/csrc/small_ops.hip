@@ -121,39 +121,59 @@ __global__ void sq_err_kernel(const float* __restrict__ a, const float* __restri
 // Written with separate multiplies/adds in the reference's order (no fma contraction across terms) so that the CPU
 // oracle and this kernel round identically given identical eps.
 // x and x_next may be the same buffer (the sampler updates in place): neither is __restrict__.
-__global__ void ddpm_step_kernel(const float* x, const float* __restrict__ eps_c,
-                                 const float* __restrict__ eps_u, const float* __restrict__ noise,
-                                 float* x_next, const float* __restrict__ coeff1,
-                                 const float* __restrict__ coeff2, const float* __restrict__ sigma,
-                                 const int32_t* __restrict__ step_ptr, float w1, float w, uint64_t seed,
-                                 int32_t* __restrict__ nan_flag, int64_t n) {
-  const int step = *step_ptr;
-  const float c1 = coeff1[step], c2 = coeff2[step], sg = sigma[step];
+struct DdpmStepK {
+  const float* x; const float* eps_c; const float* eps_u; const float* noise; float* x_next;
+  const float* coeff1; const float* coeff2; const float* sigma;
+  int32_t* step_ptr; int T; float w1, w; uint64_t seed; int32_t* nan_flag; int64_t n;
+  float* x_dup0; float* x_dup1; int64_t* t_next; int t_count; unsigned* done_counter;     // loop bookkeeping (all optional)
+};
+__global__ void ddpm_step_kernel(const DdpmStepK p) {
+  int step = *p.step_ptr;
+  step = step < 0 ? 0 : (step >= p.T ? p.T - 1 : step);        // never index outside the schedule tables, whatever the counter holds
+  const float c1 = p.coeff1[step], c2 = p.coeff2[step], sg = p.sigma[step];
   const bool add_noise = step > 0;
+  const float* x = p.x;
+  float* x_next = p.x_next;
   bool bad = false;
-  const int64_t nq = (n + 3) >> 2;
+  const int64_t n = p.n, nq = (n + 3) >> 2;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i0 = q << 2;
     float z[4] = {0.f, 0.f, 0.f, 0.f};
-    if (add_noise && noise == nullptr) {
-      const float4 zz = normal4(seed, (uint64_t)q, (uint64_t)(uint32_t)step);
+    if (add_noise && p.noise == nullptr) {
+      const float4 zz = normal4(p.seed, (uint64_t)q, (uint64_t)(uint32_t)step);
       z[0] = zz.x; z[1] = zz.y; z[2] = zz.z; z[3] = zz.w;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t i = i0 + e;
       if (i < n) {
-        if (add_noise && noise != nullptr) z[e] = noise[i];
-        const float eps = w1 * eps_c[i] - w * eps_u[i];
+        if (add_noise && p.noise != nullptr) z[e] = p.noise[i];
+        const float eps = p.w1 * p.eps_c[i] - p.w * p.eps_u[i];
         const float mean = c1 * x[i] - c2 * eps;
         const float v = add_noise ? mean + sg * z[e] : mean;
         bad |= (v != v);
         x_next[i] = v;
+        if (p.x_dup0) p.x_dup0[i] = v;
+        if (p.x_dup1) p.x_dup1[i] = v;
       }
     }
   }
   if (__any(bad)) {
-    if ((threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+    if ((threadIdx.x & 63) == 0) atomicOr(p.nan_flag, 1);
+  }
+  // Loop bookkeeping of the captured sampler step (DiffusionCondition.py:87-89: `for time_step in reversed(range(T))`,
+  // `t = x_t.new_ones([B]) * time_step`): the workgroup that finishes LAST -- every other one has read *step_ptr by then --
+  // decrements the device-resident step and writes the next step's time vector.  The counter wraps back to 0 by itself.
+  if (p.done_counter != nullptr) {
+    __shared__ int is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicInc(p.done_counter, gridDim.x - 1) == gridDim.x - 1;
+    __syncthreads();
+    if (is_last) {
+      const int next = *p.step_ptr - 1;
+      for (int i = threadIdx.x; i < p.t_count; i += blockDim.x) p.t_next[i] = (int64_t)(next < 0 ? 0 : next);
+      if (threadIdx.x == 0) *p.step_ptr = next;
+    }
   }
 }
 
@@ -311,13 +331,30 @@ int hdiff_sq_err(const float* a, const float* b, float* out, int64_t n, hdiff_st
 }
 
 int hdiff_ddpm_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, float* x_next,
-                    const float* coeff1, const float* coeff2, const float* sigma, const int32_t* step_ptr, double w,
+                    const float* coeff1, const float* coeff2, const float* sigma, const int32_t* step_ptr, int T, double w,
                     uint64_t seed, int32_t* nan_flag, int64_t n, hdiff_stream_t stream) {
   HDIFF_CHECK_ARG(x && eps_c && eps_u && x_next && coeff1 && coeff2 && sigma && step_ptr && nan_flag,
                   "ddpm_step: null pointer");
+  HDIFF_CHECK_ARG(T > 0 && n > 0, "ddpm_step: bad sizes T=%d n=%lld", T, (long long)n);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, x, eps_c, eps_u, noise,
-                     x_next, coeff1, coeff2, sigma, step_ptr, (float)(1.0 + w), (float)w, seed, nan_flag, n);
+  DdpmStepK k{x, eps_c, eps_u, noise, x_next, coeff1, coeff2, sigma, const_cast<int32_t*>(step_ptr), T, (float)(1.0 + w),
+              (float)w, seed, nan_flag, n, nullptr, nullptr, nullptr, 0, nullptr};
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, k);
+  HDIFF_CHECK_LAUNCH("ddpm_step_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_ddpm_step_loop(const hdiff_ddpm_loop_desc* d, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(d && d->x && d->eps_c && d->eps_u && d->x_next && d->coeff1 && d->coeff2 && d->sigma && d->step_ptr &&
+                      d->nan_flag && d->done_counter,
+                  "ddpm_step_loop: null pointer");
+  HDIFF_CHECK_ARG(d->T > 0 && d->n > 0 && d->t_count >= 0 && (d->t_count == 0 || d->t_next),
+                  "ddpm_step_loop: bad sizes T=%d n=%lld t_count=%d", d->T, (long long)d->n, d->t_count);
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  DdpmStepK k{d->x, d->eps_c, d->eps_u, d->noise, d->x_next, d->coeff1, d->coeff2, d->sigma, d->step_ptr, d->T,
+              (float)(1.0 + d->w), (float)d->w, d->seed, d->nan_flag, d->n, d->x_dup0, d->x_dup1, d->t_next, d->t_count,
+              d->done_counter};
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for(d->n, 4)), dim3(256), 0, (hipStream_t)stream, k);
   HDIFF_CHECK_LAUNCH("ddpm_step_kernel");
   return HDIFF_OK;
 }

@@ -64,7 +64,8 @@ class _StepPlan:
             # noise: injected buffer (parity runs) or drawn in-kernel (Philox, counter = (seed, step, element))
             p.call("hdiff_ddpm_step", up.y.data_ptr(), up.out.data_ptr(), up.out.data_ptr(),
                    self.noise.data_ptr() if inject_noise else None, up.y.data_ptr(), self.c1.data_ptr(), self.c2.data_ptr(),
-                   self.sigma.data_ptr(), self.step.data_ptr(), C.c_double(0.0), C.c_uint64(seed), self.nan_flag.data_ptr(), n)
+                   self.sigma.data_ptr(), self.step.data_ptr(), int(sampler.T), C.c_double(0.0), C.c_uint64(seed),
+                   self.nan_flag.data_ptr(), n)
         else:
             step = int(1000 / ddim_step)                                                           # :243-247
             seq = list(range(0, 1000, step))
@@ -81,10 +82,10 @@ class _StepPlan:
             self.tab = torch.stack([(1 - at).sqrt(), at.sqrt(), at_next.sqrt(), c2], dim=1).contiguous()
             self.t_tab = torch.tensor(seq, dtype=torch.int32, device=device)
             self.n_steps = len(seq)
-            p.call("hdiff_fill_from_table", up.t.data_ptr(), self.t_tab.data_ptr(), self.step.data_ptr(), B)
+            p.call("hdiff_fill_from_table", up.t.data_ptr(), self.t_tab.data_ptr(), self.step.data_ptr(), self.n_steps, B)
             p.ops.extend(up.plan.ops)
             p.call("hdiff_ddim_step", up.y.data_ptr(), up.out.data_ptr(), up.y.data_ptr(), self.tab.data_ptr(),
-                   self.step.data_ptr(), self.nan_flag.data_ptr(), n)
+                   self.step.data_ptr(), self.n_steps, self.nan_flag.data_ptr(), n)
         p.call("hdiff_step_decrement", self.step.data_ptr())
         self.plan = p
 

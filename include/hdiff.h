@@ -223,8 +223,32 @@ int hdiff_sq_err_bwd(const float* a, const float* b, const float* dloss, float* 
  * noise == NULL z is drawn in-kernel (Philox4x32-10 + Box-Muller, counter = (seed, step, element)).  nan_flag (int32)
  * is OR-ed with 1 if any output is NaN (the reference's per-step assert, :96, evaluated once after the loop). */
 int hdiff_ddpm_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, float* x_next,
-                    const float* coeff1, const float* coeff2, const float* sigma, const int32_t* step_ptr, double w,
+                    const float* coeff1, const float* coeff2, const float* sigma, const int32_t* step_ptr,
+                    int T /* length of the three tables: the step read from step_ptr is clamped into [0, T) */, double w,
                     uint64_t seed, int32_t* nan_flag, int64_t n, hdiff_stream_t stream);
+/* The same update with the loop's bookkeeping folded in, so that one captured denoising step is the UNet launches plus
+ * this ONE kernel (DiffusionCondition.py:87-96).  After the update the workgroup that finishes last
+ *   - writes the next time step, *step_ptr - 1, to *step_ptr and (clamped at 0) to t_next[0 .. t_count): the time vector
+ *     `t = x_t.new_ones([B]) * time_step` (:89) of the next replay;
+ * and every workgroup also stores x_next to x_dup0 / x_dup1 when they are given (the two halves of the 2B-batched
+ * cond + uncond UNet input of the next step, :76-77).  done_counter: one uint32 in device memory, zero before the first
+ * launch; it counts finished workgroups and wraps back to zero by itself (no reset between replays). */
+typedef struct hdiff_ddpm_loop_desc {
+  const float* x; const float* eps_c; const float* eps_u;
+  const float* noise;                 /* NULL: in-kernel Philox noise */
+  float* x_next;
+  const float* coeff1; const float* coeff2; const float* sigma;   /* [T] fp32 */
+  int32_t* step_ptr;
+  int T;
+  double w;
+  uint64_t seed;
+  int32_t* nan_flag;
+  int64_t n;
+  float* x_dup0; float* x_dup1;       /* optional */
+  int64_t* t_next; int t_count;       /* optional (t_count = 0) */
+  uint32_t* done_counter;
+} hdiff_ddpm_loop_desc;
+int hdiff_ddpm_step_loop(const hdiff_ddpm_loop_desc* d, hdiff_stream_t stream);
 /* step bookkeeping for the captured loop: t[b] = *step for all b (int64 vector for the embedding gather) */
 int hdiff_fill_t(int64_t* t, const int32_t* step_ptr, int B, hdiff_stream_t stream);
 int hdiff_step_decrement(int32_t* step_ptr, hdiff_stream_t stream);
@@ -241,8 +265,10 @@ int hdiff_step_decrement(int32_t* step_ptr, hdiff_stream_t stream);
  *                          Diffusion.py:229,252 (3 + 3 channels: too narrow for the conv's two-pointer input)
  * ------------------------------------------------------------------------------------------------------------------ */
 int hdiff_ddim_step(const float* y, const float* eps, float* y_next, const float* tab, const int32_t* step_ptr,
-                    int32_t* nan_flag, int64_t n, hdiff_stream_t stream);
-int hdiff_fill_from_table(int64_t* dst, const int32_t* table, const int32_t* idx, int n, hdiff_stream_t stream);
+                    int nsteps /* rows of tab: k = *step_ptr is clamped into [0, nsteps) */, int32_t* nan_flag, int64_t n,
+                    hdiff_stream_t stream);
+int hdiff_fill_from_table(int64_t* dst, const int32_t* table, const int32_t* idx, int table_len /* *idx is clamped */, int n,
+                          hdiff_stream_t stream);
 int hdiff_resize_nearest(const float* x, float* y, int BC, int H, int W, int OH, int OW, hdiff_stream_t stream);
 int hdiff_avgpool_global(const float* x, float* y, int BC, int HW, hdiff_stream_t stream);
 int hdiff_concat2(const float* a, const float* b, float* out, int B, int64_t n0, int64_t n1, hdiff_stream_t stream);

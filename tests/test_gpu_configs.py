@@ -432,9 +432,7 @@ def test_c5_sampler_step_512_at_batch_8():
             sp.unet.plan.pack_weights()
             outs = []
             for _ in range(2 if graph else 1):
-                sp.x.copy_(x); sp.noise.copy_(noise)
-                sp.unet.labels.copy_(torch.cat([lab, torch.zeros_like(lab)]))
-                sp.step.fill_(T - 1); sp.nan_flag.zero_()
+                sp.reset(x, lab); sp.noise.copy_(noise)
                 if graph:
                     plan.capture(); plan.replay()
                 else:

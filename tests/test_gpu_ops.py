@@ -337,7 +337,7 @@ def test_ddpm_step_bit_exact_and_nan_flag():
         st = torch.tensor([step], dtype=torch.int32, device=DEV)
         out = torch.empty(n, device=DEV)
         _capi.check(lib.hdiff_ddpm_step(dx.data_ptr(), dec.data_ptr(), deu.data_ptr(), dz.data_ptr(), out.data_ptr(),
-                                        dc1.data_ptr(), dc2.data_ptr(), dsg.data_ptr(), st.data_ptr(), C.c_double(w),
+                                        dc1.data_ptr(), dc2.data_ptr(), dsg.data_ptr(), st.data_ptr(), T, C.c_double(w),
                                         C.c_uint64(0), flag.data_ptr(), n, s))
         eps = (1. + w) * ec - w * eu                          # DiffusionCondition.py:78
         mean = c1[step] * x - c2[step] * eps                  # :68-70
@@ -347,9 +347,56 @@ def test_ddpm_step_bit_exact_and_nan_flag():
     dec[5] = float("nan")
     st = torch.tensor([3], dtype=torch.int32, device=DEV)
     _capi.check(lib.hdiff_ddpm_step(dx.data_ptr(), dec.data_ptr(), deu.data_ptr(), dz.data_ptr(), out.data_ptr(),
-                                    dc1.data_ptr(), dc2.data_ptr(), dsg.data_ptr(), st.data_ptr(), C.c_double(w),
+                                    dc1.data_ptr(), dc2.data_ptr(), dsg.data_ptr(), st.data_ptr(), T, C.c_double(w),
                                     C.c_uint64(0), flag.data_ptr(), n, s))
     assert flag.item() == 1
+    # a step counter outside the schedule is clamped, never an out-of-bounds read of the tables
+    dec[5] = 0.0
+    for bad_step, as_step in ((-7, 0), (10 ** 6, T - 1)):
+        st = torch.tensor([bad_step], dtype=torch.int32, device=DEV)
+        _capi.check(lib.hdiff_ddpm_step(dx.data_ptr(), dec.data_ptr(), deu.data_ptr(), dz.data_ptr(), out.data_ptr(),
+                                        dc1.data_ptr(), dc2.data_ptr(), dsg.data_ptr(), st.data_ptr(), T, C.c_double(w),
+                                        C.c_uint64(0), flag.data_ptr(), n, s))
+        eps = (1. + w) * dec.cpu() - w * eu
+        mean = c1[as_step] * x - c2[as_step] * eps
+        assert torch.equal(out.cpu(), mean + sg[as_step] * z if as_step > 0 else mean)
+
+
+def test_ddpm_step_loop_bookkeeping():
+    """hdiff_ddpm_step_loop = the same update + the loop's bookkeeping in one launch: x_next also lands in the two halves of
+    the next UNet input, the device-resident step goes down by one and the time vector is refilled -- by the LAST workgroup
+    to finish, replay after replay without a reset of its counter."""
+    g = torch.Generator().manual_seed(3)
+    B, per = 3, 3 * 40 * 36
+    n, T, w = B * per, 20, 1.8
+    x, ec, eu = [torch.randn(n, generator=g).to(DEV) for _ in range(3)]
+    sched = O.sampler_schedule(1e-4, 0.028, T)
+    c1, c2 = sched["coeff1"].float().to(DEV), sched["coeff2"].float().to(DEV)
+    sg = torch.sqrt(O.sampler_variance_table(sched).float()).to(DEV)
+    lib, s = _capi.lib(), torch.cuda.current_stream().cuda_stream
+    step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    done = torch.zeros(1, dtype=torch.int32, device=DEV)
+    t_next = torch.full((2 * B,), -5, dtype=torch.int64, device=DEV)
+    z = torch.randn(n, generator=g).to(DEV)
+    xin = torch.zeros(2 * n, device=DEV)
+    cur = x.clone()
+    d = _capi.DdpmLoopDesc()
+    d.x, d.eps_c, d.eps_u, d.noise, d.x_next = cur.data_ptr(), ec.data_ptr(), eu.data_ptr(), z.data_ptr(), cur.data_ptr()
+    d.coeff1, d.coeff2, d.sigma, d.step_ptr, d.T = c1.data_ptr(), c2.data_ptr(), sg.data_ptr(), step.data_ptr(), T
+    d.w, d.seed, d.nan_flag, d.n = w, 0, flag.data_ptr(), n
+    d.x_dup0, d.x_dup1, d.t_next, d.t_count, d.done_counter = xin.data_ptr(), xin.data_ptr() + 4 * n, t_next.data_ptr(), 2 * B, done.data_ptr()
+    want = x.clone()
+    for k, (t_now, t_after) in enumerate(((2, 1), (1, 0), (0, -1))):
+        _capi.check(lib.hdiff_ddpm_step_loop(C.byref(d), s), "ddpm_step_loop")
+        torch.cuda.synchronize()
+        eps = (1. + w) * ec - w * eu
+        mean = c1[t_now] * want - c2[t_now] * eps
+        want = mean + sg[t_now] * z if t_now > 0 else mean
+        assert torch.equal(cur, want), k
+        assert torch.equal(xin[:n], want) and torch.equal(xin[n:], want)
+        assert int(step.item()) == t_after and t_next.tolist() == [max(t_after, 0)] * (2 * B)
+        assert int(done.item()) == 0 and int(flag.item()) == 0          # the counter wrapped back by itself
 
 
 def test_q_sample_bit_exact_and_clip():

@@ -62,7 +62,7 @@ def test_small_ops_match_torch():
         step = torch.tensor([k], dtype=torch.int32, device=DEV)
         out = torch.empty(1000, device=DEV)
         _capi.check(lib.hdiff_ddim_step(d_y.data_ptr(), d_e.data_ptr(), out.data_ptr(), d_tab.data_ptr(), step.data_ptr(),
-                                        flag.data_ptr(), 1000, stream()))
+                                        5, flag.data_ptr(), 1000, stream()))
         y0 = (yv - ev * tab[k, 0]) / tab[k, 1]
         want = tab[k, 2] * y0 + tab[k, 3] * ev
         assert torch.equal(out.cpu(), want), k
@@ -70,8 +70,11 @@ def test_small_ops_match_torch():
     tt = torch.empty(3, dtype=torch.int64, device=DEV)
     table = torch.tensor([0, 200, 400], dtype=torch.int32, device=DEV)
     _capi.check(lib.hdiff_fill_from_table(tt.data_ptr(), table.data_ptr(), torch.tensor([2], dtype=torch.int32, device=DEV).data_ptr(),
-                                          3, stream()))
+                                          3, 3, stream()))
     assert tt.tolist() == [400, 400, 400]
+    _capi.check(lib.hdiff_fill_from_table(tt.data_ptr(), table.data_ptr(), torch.tensor([9], dtype=torch.int32, device=DEV).data_ptr(),
+                                          3, 3, stream()))
+    assert tt.tolist() == [400, 400, 400]                        # an index past the table is clamped, not read
 
 
 def test_dyn_unet_small_matches_reference_golden():

@@ -34,6 +34,6 @@ step = torch.full((1,), 500, dtype=torch.int32, device=dev)
 flag = torch.zeros(1, dtype=torch.int32, device=dev)
 plan = E.Plan(dev)
 plan.call("hdiff_ddpm_step", bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr(), bufs[4].data_ptr(),
-          c.data_ptr(), c.data_ptr(), c.data_ptr(), step.data_ptr(), C.c_double(1.8), C.c_uint64(0), flag.data_ptr(), n)
+          c.data_ptr(), c.data_ptr(), c.data_ptr(), step.data_ptr(), 1000, C.c_double(1.8), C.c_uint64(0), flag.data_ptr(), n)
 ms = timeit(plan)
 print(f"ddpm_step {n} elements: {ms*1e3:.1f} us, {5*n*4/ms/1e6:.0f} GB/s over its 5 tensors")
