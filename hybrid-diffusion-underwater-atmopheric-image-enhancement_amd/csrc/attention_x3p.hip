@@ -4,12 +4,19 @@
 // nn.MultiheadAttention core, ModelCondition.py:189, 204-208); same fixed softmax reference point, overflow poisoning and
 // check pass.
 //
-// Why a second split-bf16 kernel (measured, tools/mfma_bf16_coexec32.hip and profiles/): the bf16 MFMA shares the SIMD's
-// vector issue with the VALU for a FIXED ~8 cycles per instruction, whatever its shape.  The 16x16x32 kernel issues 96 MFMAs
-// of 16 cycles per 64x64 scores of a wave, so half of the matrix time can never hide VALU work; the 32x32x16 shape needs 56
-// MFMAs of 32 cycles for the same scores and leaves 3/4 of the matrix time to the exp / split instructions, which are what
-// bounds this formulation (about 34 VALU cycles per score and lane).  What else moved out of the loop: the K / V / Q splits
-// (done once per tensor here, not once per workgroup: 256 workgroups of a (head, sample) pair used to repeat them).
+// What the pre-split buys (measured at L = 65 536 / 16 384, tools/x3_check.py, split pass included): the K / V / Q splits
+// leave the loop -- 256 workgroups of a (head, sample) pair used to repeat them -- and with them about 10 % of its vector
+// instructions, which is what bounds this formulation: per score and lane 2 exp slots + 5.5 split / pack instructions + the
+// row sum, about 34 VALU cycles, against 24 cycles of bf16 MFMA, and on gfx950 the two overlap only by a few vector
+// instructions per MFMA (tools/mfma_bf16_coexec32.hip: beside one 32-cycle MFMA about five plain VALU instructions are
+// free, each further one costs its full 4-5 cycles, whatever the MFMA shape and however many waves share the SIMD).
+// Two kernels read the workspace:
+//   d_head 32: the 32x32x16 kernel below -- M = 32 = d, every MFMA row useful, a quarter fewer MFMA issue slots than the
+//              16x16x32 form: 217-220 TFLOP/s fp32-equivalent against 197 for the kernel that splits in its loop;
+//   d_head 16: the 16x16x32 kernel of attention_x3.hip with PRE = true (185 against 177).  This file's kernel also runs
+//              d_head 16 (HDIFF_X3P=16), where a 32-row tile carries TWO V pieces; it then spends 8 MFMA slots on 6
+//              products and measured 162 (straight order) / 174 (QK of the next unit and PV of the previous one software-
+//              pipelined beside the exp / split stream, one basic block per tile: removed again, it did not pay).
 //
 //   workspace (bf16), per (sample, head):  Qs[3][L][D] (pre-scaled into the exp2 domain), Ks[3][L][D], Vs[3][D][L]
 //   S^T = K Q^T : M = 32 keys, N = 32 queries, K = 16 of d; the six piece products accumulate in one chain that starts
@@ -29,9 +36,6 @@ using namespace hdiff;
 
 namespace {
 
-#ifndef X3P_VALU_PER_UNIT
-#define X3P_VALU_PER_UNIT 112      // vector instructions of one unit's exp / split stream (spread over its MFMAs)
-#endif
 constexpr int KT = 64;
 constexpr int THREADS = 256;
 constexpr float OVERFLOW_LIMIT = 1.2379400e27f;   // 2^90, as in attention.hip
@@ -110,9 +114,7 @@ __global__ __launch_bounds__(THREADS) void qkv_split3_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// PIPE: the software-pipelined main loop (d_head 16; at d_head 32 its register set does not fit two waves per SIMD and the
-// straight per-block order below is used, which already matches no-waste M = 32 tiles).
-template <int D, bool PIPE>
+template <int D>
 __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __bf16* __restrict__ ws, float* __restrict__ out,
                                                                       float* __restrict__ lse2, int C, int L) {
   static_assert(D == 16 || D == 32, "head dim");
@@ -289,122 +291,48 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
       }
     }
   };
-  // One MFMA, then its share of the unit's VALU instructions: the bf16 MFMA hides only a few vector instructions each
-  // (tools/mfma_bf16_coexec32.hip), so the matrix work has to be spread evenly through the exp / split stream.
-  auto interleave = [&](auto nm_tag) {
-    constexpr int nm = decltype(nm_tag)::value;
+  // ---- straight order: per 32-key block and query group  QK^T -> exp / split -> P.V  (the two waves of a SIMD overlap
+  // each other's phases)
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  stage_load(ntiles > 1 ? 1 : 0);
+  {
+    u32x4 K0[3][KS];
+    load_k(0, 0, K0);
+    const f32x16 s0 = qk(K0, 0, negm16), s1 = qk(K0, 1, negm16);       // C = 0 here
+    float tm = fmaxf(s0[0], s1[0]);
 #pragma unroll
-    for (int i = 0; i < nm; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, X3P_VALU_PER_UNIT / nm, 0);
+    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(s0[r], s1[r]));
+    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm16[r] = -tm;
+  }
+  auto block = [&](int buf, int kb) {
+    u32x4 kop[3][KS], vop[2][NVK];
+    load_k(buf, kb, kop);
+    load_v(buf, kb, vop);
+#pragma unroll
+    for (int G = 0; G < 2; ++G) {
+      const f32x16 S = qk(kop, G, negm16);
+      u32x4 pop[2][3];
+      softmax_split(S, G, pop);
+      pv(vop, pop, G);
     }
   };
-  constexpr int NM_QK = 6 * KS, NM_PV = 2 * NPV;
-
-  if constexpr (PIPE) {
-    // ---- prologue: tiles 0 and 1 into the two buffers; the reference point m of each query group from its first 32 keys
-    stage_load(0);
-    stage_store(0);
-    stage_load(ntiles > 1 ? 1 : 0);
-    stage_store(1);
+  block(0, 0);
+  block(0, 1);
+  stage_store(1);
+  __syncthreads();
+  for (int t = 1; t < ntiles; ++t) {
+    const int buf = t & 1;
+    stage_load((t + 1 < ntiles) ? t + 1 : t);
+    block(buf, 0);
+    block(buf, 1);
+    stage_store(buf ^ 1);
     __syncthreads();
-    u32x4 Ka[3][KS], Kb[3][KS], Va[2][NVK], Vb[2][NVK], popA[2][3], popB[2][3];
-    f32x16 Sa, Sb;
-    load_k(0, 0, Ka);
-    {
-      Sa = qk(Ka, 0, negm16);                       // C = 0 here
-      Sb = qk(Ka, 1, negm16);
-      float tm = fmaxf(Sa[0], Sb[0]);
-  #pragma unroll
-      for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(Sa[r], Sb[r]));
-      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-  #pragma unroll
-      for (int r = 0; r < 16; ++r) { negm16[r] = -tm; Sa[r] -= tm; }
-    }
-
-    // ---- steady state.  Unit u = (tile, 32-key block kb, query group G); in unit u the matrix core runs QK^T of unit u + 1
-    // and P.V of unit u - 1 while the VALU turns S(u) into split P(u).  Register names alternate (Sa/Sb, popA/popB, Ka/Kb,
-    // Va/Vb) so that nothing is copied from one unit to the next.  ONE barrier per tile: after unit 2 every wave has read
-    // this tile's K / V from LDS, so unit 3 may overwrite the buffer with tile t + 2 (loaded during this tile) -- and read
-    // tile t + 1's first K block from the other buffer, written two barriers ago.
-    auto tile_body = [&](auto first_tag, int t) {
-      constexpr bool FIRST = decltype(first_tag)::value;
-      const int buf = t & 1;
-      stage_load(min(t + 2, ntiles - 1));
-      // unit 0: (kb 0, G 0)
-      load_v(buf, 0, Va);
-      Sb = qk(Ka, 1, negm16);
-      if (!FIRST) pv(Vb, popB, 1);
-      softmax_split(Sa, 0, popA);
-      interleave(std::integral_constant<int, NM_QK + (FIRST ? 0 : NM_PV)>{});
-      // unit 1: (kb 0, G 1)
-      load_k(buf, 1, Kb);
-      Sa = qk(Kb, 0, negm16);
-      pv(Va, popA, 0);
-      softmax_split(Sb, 1, popB);
-      interleave(std::integral_constant<int, NM_QK + NM_PV>{});
-      // unit 2: (kb 1, G 0)
-      load_v(buf, 1, Vb);
-      Sb = qk(Kb, 1, negm16);
-      pv(Va, popB, 1);
-      softmax_split(Sa, 0, popA);
-      interleave(std::integral_constant<int, NM_QK + NM_PV>{});
-      __syncthreads();
-      asm volatile("" : "+v"(Sb));     // keep unit 3's exp / split stream behind the barrier, beside unit 3's MFMAs
-      // unit 3: (kb 1, G 1)
-      load_k(buf ^ 1, 0, Ka);
-      Sa = qk(Ka, 0, negm16);
-      pv(Vb, popA, 0);
-      softmax_split(Sb, 1, popB);
-      interleave(std::integral_constant<int, NM_QK + NM_PV>{});
-      stage_store(buf);
-    };
-    tile_body(std::true_type{}, 0);
-    for (int t = 1; t < ntiles; ++t) tile_body(std::false_type{}, t);
-    pv(Vb, popB, 1);
-  } else {
-    // ---- straight order: per 32-key block and query group  QK^T -> exp / split -> P.V  (the two waves of a SIMD overlap
-    // each other's phases)
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    stage_load(ntiles > 1 ? 1 : 0);
-    {
-      u32x4 K0[3][KS];
-      load_k(0, 0, K0);
-      const f32x16 s0 = qk(K0, 0, negm16), s1 = qk(K0, 1, negm16);       // C = 0 here
-      float tm = fmaxf(s0[0], s1[0]);
-#pragma unroll
-      for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(s0[r], s1[r]));
-      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-#pragma unroll
-      for (int r = 0; r < 16; ++r) negm16[r] = -tm;
-    }
-    auto block = [&](int buf, int kb) {
-      u32x4 kop[3][KS], vop[2][NVK];
-      load_k(buf, kb, kop);
-      load_v(buf, kb, vop);
-#pragma unroll
-      for (int G = 0; G < 2; ++G) {
-        const f32x16 S = qk(kop, G, negm16);
-        u32x4 pop[2][3];
-        softmax_split(S, G, pop);
-        pv(vop, pop, G);
-      }
-    };
-    block(0, 0);
-    block(0, 1);
-    stage_store(1);
-    __syncthreads();
-    for (int t = 1; t < ntiles; ++t) {
-      const int buf = t & 1;
-      stage_load((t + 1 < ntiles) ? t + 1 : t);
-      block(buf, 0);
-      block(buf, 1);
-      stage_store(buf ^ 1);
-      __syncthreads();
-    }
   }
+
 
   float* obase = out + ((size_t)b * C + (size_t)head * D) * L;
 #pragma unroll
@@ -442,25 +370,29 @@ int64_t mha_fwd_x3p_workspace(int B, int C, int heads, int L) {
   return (int64_t)B * 3 * C * L * 6;
 }
 
+// Which kernel consumes the pre-split operands (both are exact to the same class; this is speed only, measured at
+// L = 65 536 / 16 384, tools/x3_check.py): d_head 32 -> the 32x32x16 kernel here (220 vs 197 TFLOP/s-equivalent: M = 32 = d,
+// no idle MFMA rows); d_head 16 -> the 16x16x32 kernel of attention_x3.hip reading the same workspace (at d = 16 the 32-row
+// tiles carry two V pieces and spend 8 MFMA slots on 6 products).  Dev knob HDIFF_X3P: 0 = never pre-split, 16 / 32 = the
+// 32x32x16 kernel for that head width only, 1 = for both.
 bool launch_mha_fwd_x3p(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
                         int64_t ws_bytes, hipStream_t stream) {
   const int64_t need = mha_fwd_x3p_workspace(B, C, heads, L);
   if (need == 0 || ws == nullptr || ws_bytes < need) return false;
   const int D = C / heads;
-  {
-    // dev knob: HDIFF_X3P=0 never, =16 / =32 only that head width, =1 every covered shape.  Unset: d_head 32 only -- at
-    // d_head 16 the kernel that splits in its loop is still the faster one (162 vs 178 TFLOP/s-equivalent, L = 65 536)
-    static const char* e = getenv("HDIFF_X3P");
-    const int sel = e ? atoi(e) : 32;
-    if (sel != D && sel != 1) return false;
-  }
+  static const char* e = getenv("HDIFF_X3P");
+  const int sel = e ? atoi(e) : 32;
+  if (sel == 0) return false;
+  const bool wide = (sel == D || sel == 1);
   dim3 sgrid(cdiv(L, 256), 3 * heads, B), grid(L / 256, heads, B);
   if (D == 16) {
     hipLaunchKernelGGL((qkv_split3_kernel<16>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);
-    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<16, true>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
+    if (!wide) return launch_mha_fwd_x3(qkv, ws, o, lse2, B, C, heads, L, qscale, stream);
+    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<16>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
   } else {
     hipLaunchKernelGGL((qkv_split3_kernel<32>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);
-    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<32, false>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
+    if (!wide) return launch_mha_fwd_x3(qkv, ws, o, lse2, B, C, heads, L, qscale, stream);
+    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<32>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
   }
   return true;
 }

@@ -81,6 +81,7 @@ int contraction_mode();   // HDIFF_CONTRACT_*
 int64_t mha_fwd_x3p_workspace(int B, int C, int heads, int L);
 bool launch_mha_fwd_x3p(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
                         int64_t ws_bytes, hipStream_t stream);
-bool launch_mha_fwd_x3(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, hipStream_t stream);
+bool launch_mha_fwd_x3(const float* qkv, const void* ws /* pre-split operands or NULL */, float* o, float* lse2, int B, int C,
+                       int heads, int L, float qscale, hipStream_t stream);
 
 }  // namespace hdiff

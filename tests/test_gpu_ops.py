@@ -237,8 +237,11 @@ def test_flash_attention_split_bf16_is_fp32_class(d, L, B, scale, workspace, bf1
     qkv = torch.randn(B, 3 * heads * d, L, generator=g) * scale
     ref = attention_core_ref(qkv, heads).double()
     o_x3, _ = _flash(lib, qkv, heads, workspace=workspace)
-    if workspace:                                        # the two split-bf16 kernels are different programs
-        assert not torch.equal(o_x3, _flash(lib, qkv, heads)[0]), "the pre-split kernel did not run"
+    if workspace:
+        # d_head 32: a different program (32x32x16 tiles, other summation order).  d_head 16: the same 16x16x32 kernel fed
+        # from the workspace -- identical pieces, identical order, so identical bits
+        same = torch.equal(o_x3, _flash(lib, qkv, heads)[0])
+        assert same == (d == 16), "the pre-split path did not run the kernel it should"
     assert lib.hdiff_get_contraction_mode() == 1
     _capi.check(lib.hdiff_set_contraction_mode(0))
     o_f32, _ = _flash(lib, qkv, heads)
