@@ -428,7 +428,7 @@ def main():
                 d = args[0]._obj
                 if d.ntaps == 9 and d.C0 == Cc and d.C1 == 0 and d.Cout == Cc and d.H == S and d.in_stride == 1:
                     groups["conv3x3"].append(i)
-            elif name == "hdiff_gn_stats" and args[5] == L_full and args[2] + args[3] == Cc:
+            elif name in ("hdiff_gn_stats", "hdiff_gn_scale_shift") and args[5] == L_full and args[2] + args[3] == Cc:
                 groups["gn_stats"].append(i)
         hooked = {i: g for g, idx in groups.items() for i in idx}
         events = {g: [] for g in groups}
@@ -563,7 +563,7 @@ def main():
                 by = 4.0 * Cc * L_full * (2 * B)                       # the activation is read once; 2*C floats written
                 ach = by / (avg * 1e-3) / 1e9
                 roof["secondary"].append({
-                    "bound": "hbm", "kernel": f"hdiff_gn_stats = gn_stats_kernel, {Cc} channels at {S}x{S}, batch {2 * B} "
+                    "bound": "hbm", "kernel": f"hdiff_gn_scale_shift = gn_stats_kernel (statistics + scale/shift fold in one launch), {Cc} channels at {S}x{S}, batch {2 * B} "
                                               "(inside the step its input was just written by the producing conv: partly "
                                               "L2 / Infinity-Cache resident; cold-HBM rate: profiles/, tools/gn_once.py)",
                     "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),

@@ -189,6 +189,7 @@ class ResBlock(nn.Module, _EagerMixin):
         plan = E.Plan(x.device)
         has_attn = isinstance(self.attn, nn.MultiheadAttention)
         out = E.emit_resblock(plan, _params_of(self, "m."), "m", x, None, temb, cemb, self.out_ch, B, H, W, has_attn)
+        plan.flush_block_vecs(0, temb, cemb, B)
         return self._finish(plan, out)
 
 

@@ -28,9 +28,45 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// Merge the partials of one (sample, group) and write the per-channel scale / shift; every lane does the same arithmetic
+// (Chan merge, sequential over the few partials), lanes share the channels.
+__device__ __forceinline__ void gn_finalize_group(const float* __restrict__ ws, int bg, int C, int G, int nsplit,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                  float* __restrict__ scale, float* __restrict__ shift,
+                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out, int lane) {
+  const int b = bg / G, g = bg - b * G;
+  const int cpg = C / G;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* p = ws + ((size_t)bg * nsplit + s) * 3;
+    const float nb = p[0], mb = p[1], m2b = p[2];
+    if (nb > 0.f) {
+      const float tot = n + nb;
+      const float delta = mb - mean;
+      mean += delta * (nb / tot);
+      m2 += m2b + delta * delta * (n * nb / tot);
+      n = tot;
+    }
+  }
+  const float var = m2 / n;
+  const float rstd = rsqrtf(var + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[bg] = mean;
+    if (rstd_out) rstd_out[bg] = rstd;
+  }
+  for (int cc = lane; cc < cpg; cc += 64) {
+    const int c = g * cpg + cc;
+    const float sc = rstd * gamma[c];
+    scale[b * C + c] = sc;
+    shift[b * C + c] = beta[c] - mean * sc;
+  }
+}
+
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                               int C0, int C1, int HW, int G, int nsplit,
-                                                              float* __restrict__ ws) {
+                                                              float* __restrict__ ws, unsigned* __restrict__ counters,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float eps, float* __restrict__ scale, float* __restrict__ shift) {
   __shared__ float red[GN_THREADS / 64];
   const int bg = blockIdx.x, split = blockIdx.y;
   const int b = bg / G, g = bg - b * G;
@@ -81,43 +117,32 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __res
     o[1] = mean;
     o[2] = m2;
   }
+  // Fused finalize (hdiff_gn_scale_shift): the workgroup of a (sample, group) that finishes LAST merges the partials -- no
+  // second launch.  Producer side: the partial is stored, released at agent scope, then the counter is bumped; consumer
+  // side: agent-scope acquire before the partials of the other workgroups (other CUs, maybe other XCDs) are read.  The
+  // counter wraps to 0 by itself (atomicInc), so the buffer is zeroed once, not per launch.
+  if (counters != nullptr) {
+    __shared__ int is_last;
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const unsigned prev = nsplit > 1 ? atomicInc(&counters[bg], (unsigned)nsplit - 1u) : 0u;
+      is_last = prev == (unsigned)nsplit - 1u;
+      if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (is_last && threadIdx.x < 64)
+      gn_finalize_group(ws, bg, C, G, nsplit, gamma, beta, eps, scale, shift, nullptr, nullptr, threadIdx.x);
+  }
 }
 
-// One wave per (sample, group): merge partials, then write the per-channel scale/shift.
+// One wave per (sample, group).
 __global__ void gn_finalize_kernel(const float* __restrict__ ws, int B, int C, int G, int nsplit,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
                                    float* __restrict__ rstd_out) {
   const int bg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (bg >= B * G) return;
-  const int lane = threadIdx.x & 63;
-  const int b = bg / G, g = bg - b * G;
-  const int cpg = C / G;
-  // Chan merge, sequential over the (few) partials; every lane does the same arithmetic
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float* p = ws + ((size_t)bg * nsplit + s) * 3;
-    const float nb = p[0], mb = p[1], m2b = p[2];
-    if (nb > 0.f) {
-      const float tot = n + nb;
-      const float delta = mb - mean;
-      mean += delta * (nb / tot);
-      m2 += m2b + delta * delta * (n * nb / tot);
-      n = tot;
-    }
-  }
-  const float var = m2 / n;
-  const float rstd = rsqrtf(var + eps);
-  if (lane == 0) {
-    if (mean_out) mean_out[bg] = mean;
-    if (rstd_out) rstd_out[bg] = rstd;
-  }
-  for (int cc = lane; cc < cpg; cc += 64) {
-    const int c = g * cpg + cc;
-    const float sc = rstd * gamma[c];
-    scale[b * C + c] = sc;
-    shift[b * C + c] = beta[c] - mean * sc;
-  }
+  gn_finalize_group(ws, bg, C, G, nsplit, gamma, beta, eps, scale, shift, mean_out, rstd_out, threadIdx.x & 63);
 }
 
 // y = x * scale[b][c] + shift[b][c]: GroupNorm WITHOUT the Swish (the reference's AttnBlock normalises and projects,
@@ -151,8 +176,23 @@ extern "C" int hdiff_gn_stats(const float* x0, const float* x1, int C0, int C1, 
   HDIFF_CHECK_ARG(B > 0 && HW > 0 && nsplit >= 1 && nsplit <= 1024, "gn_stats: bad sizes");
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   hipLaunchKernelGGL(gn_stats_kernel, dim3(B * G, nsplit), dim3(GN_THREADS), 0, (hipStream_t)stream, x0, x1, C0, C1, HW,
-                     G, nsplit, ws);
+                     G, nsplit, ws, (unsigned*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr,
+                     (float*)nullptr);
   HDIFF_CHECK_LAUNCH("gn_stats_kernel");
+  return HDIFF_OK;
+}
+
+extern "C" int hdiff_gn_scale_shift(const float* x0, const float* x1, int C0, int C1, int B, int HW, int G, int nsplit,
+                                    float* ws, uint32_t* counters, const float* gamma, const float* beta, float eps,
+                                    float* scale, float* shift, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(x0 && ws && counters && gamma && beta && scale && shift, "gn_scale_shift: null pointer");
+  HDIFF_CHECK_ARG(C1 == 0 || x1, "gn_scale_shift: C1 > 0 without x1");
+  HDIFF_CHECK_ARG(G > 0 && (C0 + C1) % G == 0, "gn_scale_shift: channels %d not divisible by %d groups", C0 + C1, G);
+  HDIFF_CHECK_ARG(B > 0 && HW > 0 && nsplit >= 1 && nsplit <= 1024, "gn_scale_shift: bad sizes");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(B * G, nsplit), dim3(GN_THREADS), 0, (hipStream_t)stream, x0, x1, C0, C1, HW,
+                     G, nsplit, ws, (unsigned*)counters, gamma, beta, eps, scale, shift);
+  HDIFF_CHECK_LAUNCH("gn_stats_kernel (fused finalize)");
   return HDIFF_OK;
 }
 

@@ -40,6 +40,43 @@ __global__ void linear_rows_kernel(const float* __restrict__ x, const int64_t* _
   }
 }
 
+// All per-block projections of the time / label embeddings in ONE launch (ResBlock.forward, ModelCondition.py:199-200:
+// h += temb_proj(temb)[:, :, None, None]; h += cond_proj(cemb)[:, :, None, None], each Swish -> Linear): job j computes
+//   y_j[b][n] = (sum_k swish(x0[b][k]) w0_j[n][k] + b0_j[n]) + (sum_k swish(x1[b][k]) w1_j[n][k] + b1_j[n])
+// with the SAME roundings as the two accumulating linear_rows launches it replaces (each dot product reduced on its own,
+// bias added, then the two results added).  One wave per output; the job of a wave is found from the prefix table.
+__global__ void linear_rows_multi_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                         const hdiff_linear_job* __restrict__ jobs, int njobs, int total_n, int B, int K) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= B * total_n) return;
+  const int b = wave / total_n, gn = wave - b * total_n;
+  int j = 0;
+  while (j + 1 < njobs && jobs[j + 1].first <= gn) ++j;          // wave-uniform, at most a few dozen jobs
+  const hdiff_linear_job job = jobs[j];
+  const int n = gn - job.first;
+  const float* xr0 = x0 + (size_t)b * K;
+  const float* wr0 = job.w0 + (size_t)n * K;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s = fmaf(wr0[k], swishf(xr0[k]), s);
+  s = wave_sum(s);
+  float t = 0.f;
+  if (job.w1 != nullptr) {
+    const float* xr1 = x1 + (size_t)b * K;
+    const float* wr1 = job.w1 + (size_t)n * K;
+    for (int k = lane; k < K; k += 64) t = fmaf(wr1[k], swishf(xr1[k]), t);
+    t = wave_sum(t);
+  }
+  if (lane == 0) {
+    if (job.b0) s += job.b0[n];
+    if (job.w1 != nullptr) {
+      if (job.b1) t += job.b1[n];
+      s = s + t;
+    }
+    job.y[(size_t)b * job.n + n] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter-based generator + Box-Muller: 4 normals per counter.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -356,6 +393,17 @@ int hdiff_ddpm_step_loop(const hdiff_ddpm_loop_desc* d, hdiff_stream_t stream) {
               d->done_counter};
   hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for(d->n, 4)), dim3(256), 0, (hipStream_t)stream, k);
   HDIFF_CHECK_LAUNCH("ddpm_step_kernel");
+  return HDIFF_OK;
+}
+
+int hdiff_linear_rows_multi(const float* x0, const float* x1, const hdiff_linear_job* jobs, int njobs, int total_n, int B,
+                            int K, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(x0 && jobs && njobs > 0 && total_n > 0 && B > 0 && K > 0, "linear_rows_multi: bad arguments");
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  const int64_t waves = (int64_t)B * total_n;
+  hipLaunchKernelGGL(linear_rows_multi_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x0, x1,
+                     jobs, njobs, total_n, B, K);
+  HDIFF_CHECK_LAUNCH("linear_rows_multi_kernel");
   return HDIFF_OK;
 }
 

@@ -70,6 +70,7 @@ class ResBlock(nn.Module, _EagerMixin):
         B, _, H, W = (int(v) for v in x.shape)
         plan = E.Plan(x.device)
         out = E.emit_resblock(plan, _params_of(self, "m."), "m", x, None, temb, cemb, self.out_ch, B, H, W, self.activate_attn)
+        plan.flush_block_vecs(0, temb, cemb, B)
         return self._finish(plan, out)
 
 

@@ -8,8 +8,9 @@ preallocated buffers -- no allocation or synchronisation while it runs -- so a p
 The UNet emitter walks the architecture of the reference's ``UNet`` (ModelCondition.py:213-276) and maps it to launches:
 
   ResBlock (ModelCondition.py:196-211)          launches
-    GroupNorm+Swish+Conv3x3 (+temb +cemb)   ->  gn_stats, gn_finalize, 2x linear_rows, conv(prologue=GN/Swish, epilogue=+bias+vec)
-    GroupNorm+Swish+Dropout+Conv3x3 + shortcut -> gn_stats, gn_finalize, [conv1x1 shortcut], conv(prologue, epilogue=+residual)
+    GroupNorm+Swish+Conv3x3 (+temb +cemb)   ->  gn_scale_shift (stats + fold, one launch), conv(prologue=GN/Swish, epilogue=+bias+vec);
+                                                the temb / cemb projections of ALL blocks are one launch behind the embedding MLPs
+    GroupNorm+Swish+Dropout+Conv3x3 + shortcut -> gn_scale_shift, [conv1x1 shortcut], conv(prologue, epilogue=+residual)
     MultiheadAttention                      ->  conv1x1 (packed in-proj) -> mha_flash_fwd -> conv1x1 (out-proj)
   DownSample (:74-76)  c1(x)+c2(x)          ->  ONE 5x5/s2 conv: the 3x3 weights are folded into the 5x5 centre at pack time
   UpSample (:85-89)    ConvTranspose 5x5/s2 ->  4 output-parity phases (3x3, 3x2, 2x3, 2x2 taps) as stride-1 convs, then conv3x3
@@ -135,6 +136,8 @@ class Plan:
         self.graph = C.c_void_p(None)
         self._graph_stream: Optional[torch.cuda.Stream] = None
         self.flops = 0.0          # algorithmic FLOPs of the MFMA-bound launches (convolutions, attention) of one run
+        self._vec_jobs: List[tuple] = []          # per-block embedding projections, emitted as ONE launch (flush_block_vecs)
+        self._gn_counters: Optional[torch.Tensor] = None
 
     # -- memory -------------------------------------------------------------------------------------------------------
     def buf(self, *shape: int, dtype=torch.float32) -> torch.Tensor:
@@ -170,6 +173,7 @@ class Plan:
     def run(self, stream: Optional[int] = None) -> None:
         # launches go to the plan's device whatever the caller's current device is (the C ABI launches on the current
         # device; per-kernel attributes such as the dynamic-LDS limit are set per device on first use)
+        assert not self._vec_jobs, "flush_block_vecs() was not called for this plan"
         with torch.cuda.device(self.device):
             s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
             for name, fn, args in self.ops:
@@ -263,12 +267,45 @@ class Plan:
         nsplit = max(1, min(32, HW // 4096))     # a function of the plane size only: per-sample results must not depend on B
         ws = self.buf(B * GN_GROUPS * nsplit * 3)
         scale, shift = self.buf(B, Ct), self.buf(B, Ct)
-        self.call("hdiff_gn_stats", _ptr(x0), _ptr(x1), C0, C1, B, HW, GN_GROUPS, nsplit, ws.data_ptr())
-        self.call("hdiff_gn_finalize", ws.data_ptr(), B, Ct, GN_GROUPS, nsplit, gamma.data_ptr(), beta.data_ptr(),
-                  C.c_float(GN_EPS), scale.data_ptr(), shift.data_ptr(), None, None)
+        # statistics and the (mean, rstd, gamma, beta) -> scale / shift fold in one launch: the last-arriving workgroup of a
+        # (sample, group) merges the partials; the arrival counters are shared by every GroupNorm of the plan (zero between launches)
+        if self._gn_counters is None or self._gn_counters.numel() < B * GN_GROUPS:
+            self._gn_counters = torch.zeros(B * GN_GROUPS, dtype=torch.int32, device=self.device)
+        self.call("hdiff_gn_scale_shift", _ptr(x0), _ptr(x1), C0, C1, B, HW, GN_GROUPS, nsplit, ws.data_ptr(),
+                  self._gn_counters.data_ptr(), gamma.data_ptr(), beta.data_ptr(), C.c_float(GN_EPS), scale.data_ptr(),
+                  shift.data_ptr())
         self.keep((x0, x1, gamma, beta, ws))
         self.free(ws)
         return scale, shift
+
+    def block_vec(self, temb: torch.Tensor, cemb: Optional[torch.Tensor], P: Dict[str, torch.Tensor], p: str, B: int,
+                  cout: int) -> torch.Tensor:
+        """temb_proj(temb) + cond_proj(cemb) of one ResBlock (ModelCondition.py:199-200) as a [B][cout] vector for the conv
+        epilogue.  All of a plan's projections depend only on temb / cemb, so they are collected here and emitted as ONE
+        launch at the point `flush_block_vecs` is told (right behind the embedding MLPs)."""
+        vec = torch.empty(B, cout, dtype=torch.float32, device=self.device)       # lives as long as the plan: not pooled
+        wc = P[f"{p}.cond_proj.1.weight"] if cemb is not None else None
+        bc = P[f"{p}.cond_proj.1.bias"] if cemb is not None else None
+        self._vec_jobs.append((P[f"{p}.temb_proj.1.weight"], P[f"{p}.temb_proj.1.bias"], wc, bc, vec))
+        return vec
+
+    def flush_block_vecs(self, pos: int, temb: torch.Tensor, cemb: Optional[torch.Tensor], B: int) -> None:
+        """Insert the one hdiff_linear_rows_multi launch for every collected projection at op index `pos`."""
+        if not self._vec_jobs:
+            return
+        jobs = (_capi.LinearJob * len(self._vec_jobs))()
+        first = 0
+        for j, (wt, bt, wc, bc, vec) in enumerate(self._vec_jobs):
+            jobs[j].w0, jobs[j].b0, jobs[j].w1, jobs[j].b1 = wt.data_ptr(), bt.data_ptr(), _ptr(wc), _ptr(bc)
+            jobs[j].y, jobs[j].n, jobs[j].first = vec.data_ptr(), int(wt.shape[0]), first
+            first += int(wt.shape[0])
+        raw = bytes(jobs)
+        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        K = int(self._vec_jobs[0][0].shape[1])
+        self.keep((table, temb, cemb, list(self._vec_jobs)))
+        self.ops.insert(pos, ("hdiff_linear_rows_multi", getattr(self.lib, "hdiff_linear_rows_multi"),
+                              (temb.data_ptr(), _ptr(cemb), table.data_ptr(), len(self._vec_jobs), first, B, K)))
+        self._vec_jobs = []
 
     def linear(self, x: torch.Tensor, idx: Optional[torch.Tensor], W: torch.Tensor, bias: Optional[torch.Tensor],
                y: torch.Tensor, B: int, swish_input: bool, accumulate: bool) -> None:
@@ -382,14 +419,11 @@ def emit_resblock(plan: Plan, P: Dict[str, torch.Tensor], p: str, xa: torch.Tens
                   temb: torch.Tensor, cemb: Optional[torch.Tensor], cout: int, B: int, H: int, W: int, attn: bool) -> torch.Tensor:
     """ResBlock.forward (ModelCondition.py:196-211) on the virtual concat [xa | xb]."""
     sc1 = plan.gn_scale_shift(xa, xb, P[f"{p}.block1.0.weight"], P[f"{p}.block1.0.bias"], B, H * W)
-    vec = plan.buf(B, cout)
-    plan.linear(temb, None, P[f"{p}.temb_proj.1.weight"], P[f"{p}.temb_proj.1.bias"], vec, B, True, False)
-    if cemb is not None:
-        plan.linear(cemb, None, P[f"{p}.cond_proj.1.weight"], P[f"{p}.cond_proj.1.bias"], vec, B, True, True)
+    vec = plan.block_vec(temb, cemb, P, p, B, cout)
     pk1 = _std_pack(plan, P[f"{p}.block1.2.weight"], 3, 1)
     h1 = plan.buf(B, cout, H, W)
     plan.conv(xa, xb, pk1, P[f"{p}.block1.2.bias"], h1, B=B, H=H, W=W, VH=H, VW=W, gn=sc1, addvec=vec)
-    plan.free(sc1[0]); plan.free(sc1[1]); plan.free(vec)
+    plan.free(sc1[0]); plan.free(sc1[1])
 
     sc2 = plan.gn_scale_shift(h1, None, P[f"{p}.block2.0.weight"], P[f"{p}.block2.0.bias"], B, H * W)
     if f"{p}.shortcut.weight" in P:
@@ -465,6 +499,7 @@ class UNetPlan:
         ch = shape.ch
         temb = emit_embed_mlp(plan, P, "time_embedding.timembedding", self.t, B)
         cemb = emit_embed_mlp(plan, P, "cond_embedding.condEmbedding", self.labels, B)
+        vec_pos = len(plan.ops)            # the per-block projections of temb / cemb go here, as one launch
 
         pk_head = _std_pack(plan, P["head.weight"], 3, 1)
         h = plan.buf(B, ch, H, W)
@@ -507,6 +542,7 @@ class UNetPlan:
         pk_tail = _std_pack(plan, P["tail.2.weight"], 3, 1)
         self.out = plan.buf(B, 3, H, W)
         plan.conv(h, None, pk_tail, P["tail.2.bias"], self.out, B=B, H=H, W=W, VH=H, VW=W, gn=sct)
+        plan.flush_block_vecs(vec_pos, temb, cemb, B)
         plan.keep((temb, cemb, h))
 
 
@@ -579,6 +615,7 @@ class DynUNetPlan:
             cemb = emit_cond_image_embedding(plan, P, "cond_embedding", self.label, B, H, W)
             self._zero = None
 
+        vec_pos = len(plan.ops)            # the per-block projections of temb / cemb go here, as one launch
         self.x6 = plan.buf(B, 6, H, W)
         plan.call("hdiff_concat2", self.cond.data_ptr(), self.y.data_ptr(), self.x6.data_ptr(), B, 3 * H * W, 3 * H * W)
         pk_head = _std_pack(plan, P["head.weight"], 3, 1)
@@ -637,4 +674,5 @@ class DynUNetPlan:
         self.out = plan.buf(B, 3, cH, cW)
         plan.conv(h, None, pk_tail, P["tail.2.bias"], self.out, B=B, H=cH, W=cW, VH=cH, VW=cW, gn=sct)
         self.tail_in_src = (h, sct)        # kept for tests: the tensor entering the tail and its GN scale/shift
+        plan.flush_block_vecs(vec_pos, temb, cemb, B)
         plan.keep((temb, cemb, h))

@@ -146,6 +146,13 @@ int hdiff_gn_stats(const float* x0, const float* x1, int C0, int C1, int B, int 
 int hdiff_gn_finalize(const float* ws, int B, int C, int G, int nsplit, const float* gamma, const float* beta, float eps,
                       float* scale, float* shift, float* mean_out /*[B][G] or NULL*/, float* rstd_out /*[B][G] or NULL*/,
                       hdiff_stream_t stream);
+/* hdiff_gn_stats + hdiff_gn_finalize in ONE launch: the workgroup of a (sample, group) that finishes last merges the
+ * partials and writes scale / shift (agent-scope release / acquire around a per-(sample, group) arrival counter).
+ * counters: B*G uint32 in device memory, zero before the first use; every launch leaves them at zero again.  Results are
+ * bit-identical to the two-launch form (same merge order). */
+int hdiff_gn_scale_shift(const float* x0, const float* x1, int C0, int C1, int B, int HW, int G, int nsplit, float* ws,
+                         uint32_t* counters, const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                         hdiff_stream_t stream);
 /* Backward of GroupNorm + Swish (the conv prologue): dA is the gradient w.r.t. the activated tensor [B][C0+C1][HW];
  * mean/rstd [B][G] come from hdiff_gn_finalize.  Writes dx0 [B][C0][HW], dx1 [B][C1][HW], dgamma [C], dbeta [C].
  * ws: 2*B*C + 2*B*G floats. */
@@ -198,6 +205,17 @@ int hdiff_mha_flash_bwd(const float* qkv, const float* o, const float* d_o, cons
  * ------------------------------------------------------------------------------------------------------------------ */
 int hdiff_linear_rows(const float* x, const int64_t* idx, int n_rows, const float* W, const float* bias, float* y, int B,
                       int K, int N, int swish_input, int accumulate, hdiff_stream_t stream);
+/* Every per-block projection of the time and label embeddings in one launch (ResBlock.forward, ModelCondition.py:199-200):
+ *   y_j[b][n] = (sum_k swish(x0[b][k]) w0_j[n][k] + b0_j[n]) + (sum_k swish(x1[b][k]) w1_j[n][k] + b1_j[n]),  j < njobs
+ * bit-identical to hdiff_linear_rows(x0 -> y_j, swish) followed by hdiff_linear_rows(x1 -> y_j, swish, accumulate).
+ * `jobs` lives in DEVICE memory (pointers to [n][K] weights, [n] biases, the [B][n] output); jobs[j].first = sum of the n
+ * of the jobs before j; total_n = sum of all n; w1 / b1 may be NULL (no second term). */
+typedef struct hdiff_linear_job {
+  const float* w0; const float* b0; const float* w1; const float* b1; float* y;
+  int n; int first;
+} hdiff_linear_job;
+int hdiff_linear_rows_multi(const float* x0 /*[B][K]*/, const float* x1 /*[B][K] or NULL*/, const hdiff_linear_job* jobs,
+                            int njobs, int total_n, int B, int K, hdiff_stream_t stream);
 
 /* Backward of hdiff_linear_rows: dW [N][K] (+)= dy^T f(x), db [N] (+)= sum_b dy, and, if dx != NULL, dx = (dy W) o f'(x).
  * With idx != NULL, dx is the [n_rows][K] gradient of the gathered table and is ACCUMULATED into (zero it first); row

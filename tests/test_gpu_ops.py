@@ -127,6 +127,68 @@ def test_groupnorm_scale_shift(C0, C1, H, W, B):
     close(y, O.swish(O.group_norm(x, 32, gamma, beta, 1e-5)), rel=3e-5, what="gn+swish")
 
 
+@pytest.mark.parametrize("C0,C1,HW,B", [(128, 0, 65536, 2), (256, 128, 16384, 3), (64, 0, 4096, 1), (32, 0, 100, 4)])
+def test_groupnorm_fused_finalize_equals_two_launches(C0, C1, HW, B):
+    """hdiff_gn_scale_shift (the last-arriving workgroup of a (sample, group) folds the partials) against hdiff_gn_stats +
+    hdiff_gn_finalize: the same bits, launch after launch on the same arrival counters (they wrap back to zero)."""
+    g = torch.Generator(device=DEV).manual_seed(C0 + HW)
+    xa = torch.randn(B, C0, HW, device=DEV, generator=g) * 3 - 1
+    xb = torch.randn(B, C1, HW, device=DEV, generator=g) + 2 if C1 else None
+    Ct = C0 + C1
+    gamma, beta = torch.randn(Ct, device=DEV, generator=g), torch.randn(Ct, device=DEV, generator=g)
+    lib, s = _capi.lib(), torch.cuda.current_stream().cuda_stream
+    nsplit = max(1, min(32, HW // 4096))
+    ws = torch.empty(B * 32 * nsplit * 3, device=DEV)
+    sc0, sh0 = torch.empty(B, Ct, device=DEV), torch.empty(B, Ct, device=DEV)
+    px = lambda t: None if t is None else t.data_ptr()
+    _capi.check(lib.hdiff_gn_stats(px(xa), px(xb), C0, C1, B, HW, 32, nsplit, ws.data_ptr(), s))
+    _capi.check(lib.hdiff_gn_finalize(ws.data_ptr(), B, Ct, 32, nsplit, gamma.data_ptr(), beta.data_ptr(), C.c_float(1e-5),
+                                      sc0.data_ptr(), sh0.data_ptr(), None, None, s))
+    counters = torch.zeros(B * 32, dtype=torch.int32, device=DEV)
+    for rep in range(3):
+        ws2 = torch.full_like(ws, float("nan"))
+        sc1, sh1 = torch.full_like(sc0, float("nan")), torch.full_like(sh0, float("nan"))
+        _capi.check(lib.hdiff_gn_scale_shift(px(xa), px(xb), C0, C1, B, HW, 32, nsplit, ws2.data_ptr(), counters.data_ptr(),
+                                             gamma.data_ptr(), beta.data_ptr(), C.c_float(1e-5), sc1.data_ptr(), sh1.data_ptr(),
+                                             s))
+        torch.cuda.synchronize()
+        assert torch.equal(sc1, sc0) and torch.equal(sh1, sh0), rep
+        assert int(counters.abs().sum().item()) == 0
+
+
+def test_linear_rows_multi_equals_the_launches_it_replaces():
+    """All per-block projections of temb / cemb in one launch (ModelCondition.py:199-200) == per block
+    linear_rows(temb) then linear_rows(cemb, accumulate): the same bits; jobs without a second term as well."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    B, K = 5, 512
+    temb, cemb = torch.randn(B, K, device=DEV, generator=g), torch.randn(B, K, device=DEV, generator=g)
+    lib, s = _capi.lib(), torch.cuda.current_stream().cuda_stream
+    widths = [128, 128, 256, 40, 256, 3]
+    ws_ = [(torch.randn(n, K, device=DEV, generator=g) / 20, torch.randn(n, device=DEV, generator=g),
+            torch.randn(n, K, device=DEV, generator=g) / 20, torch.randn(n, device=DEV, generator=g)) for n in widths]
+    for with_second in (True, False):
+        want = []
+        for n, (w0, b0, w1, b1) in zip(widths, ws_):
+            y = torch.empty(B, n, device=DEV)
+            _capi.check(lib.hdiff_linear_rows(temb.data_ptr(), None, 0, w0.data_ptr(), b0.data_ptr(), y.data_ptr(), B, K, n, 1, 0, s))
+            if with_second:
+                _capi.check(lib.hdiff_linear_rows(cemb.data_ptr(), None, 0, w1.data_ptr(), b1.data_ptr(), y.data_ptr(), B, K, n, 1, 1, s))
+            want.append(y)
+        outs = [torch.full((B, n), float("nan"), device=DEV) for n in widths]
+        jobs = (_capi.LinearJob * len(widths))()
+        first = 0
+        for j, (n, (w0, b0, w1, b1)) in enumerate(zip(widths, ws_)):
+            jobs[j].w0, jobs[j].b0, jobs[j].y, jobs[j].n, jobs[j].first = w0.data_ptr(), b0.data_ptr(), outs[j].data_ptr(), n, first
+            jobs[j].w1, jobs[j].b1 = (w1.data_ptr(), b1.data_ptr()) if with_second else (None, None)
+            first += n
+        table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(DEV)
+        _capi.check(lib.hdiff_linear_rows_multi(temb.data_ptr(), cemb.data_ptr() if with_second else None, table.data_ptr(),
+                                                len(widths), first, B, K, s))
+        torch.cuda.synchronize()
+        for got, ref in zip(outs, want):
+            assert torch.equal(got, ref)
+
+
 def attention_core_ref(qkv, heads):
     B, C3, L = qkv.shape
     Cc = C3 // 3
