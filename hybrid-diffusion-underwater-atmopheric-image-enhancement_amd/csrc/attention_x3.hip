@@ -15,6 +15,8 @@
 //          two 16-key score tiles form the 32 contraction slots of one MFMA; V pieces come pre-split from LDS.
 //   K, V:  split once per tile by the staging threads (not per wave), stored as bf16 [piece][key][d] / [piece][d][key].
 // Softmax reference point, overflow poisoning and the safe second pass are those of mha_flash_fwd_fast_kernel.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -62,6 +64,10 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 __device__ constexpr int TERM_A[6] = {0, 1, 0, 2, 1, 0};
 __device__ constexpr int TERM_B[6] = {0, 0, 1, 0, 1, 2};
 
+// (Tried on top of PRE and removed: a schedule pipelined ACROSS key tiles -- QK^T of the next tile's first query tile in
+// the last stage, P.V of the previous tile's last one in the first, three LDS buffers, one barrier -- so that every stage
+// has 24 MFMAs beside its exp / split stream.  The compiler clumps the MFMAs of such a body whatever the
+// sched_group_barrier pattern (256 registers): 171-173 TFLOP/s-equivalent against 179 for this per-tile schedule, same box.)
 // PRE: Q, K, V arrive already split into bf16 pieces (the workspace written by qkv_split3_kernel, attention_x3p.hip:
 // per (sample, head) Qs[3][L][D] pre-scaled, Ks[3][L][D], Vs[3][D][L]) -- the staging threads then only copy, and the ~10 %
 // of the loop's vector instructions that re-split K / V in every one of the 256 workgroups of a (head, sample) are gone.
