@@ -563,7 +563,7 @@ def main():
                 by = 4.0 * Cc * L_full * (2 * B)                       # the activation is read once; 2*C floats written
                 ach = by / (avg * 1e-3) / 1e9
                 roof["secondary"].append({
-                    "bound": "hbm", "kernel": f"hdiff_gn_scale_shift = gn_stats_kernel (statistics + scale/shift fold in one launch), {Cc} channels at {S}x{S}, batch {2 * B} "
+                    "bound": "hbm", "kernel": f"hdiff_gn_scale_shift = gn_stats_kernel + the small merge kernel, {Cc} channels at {S}x{S}, batch {2 * B} "
                                               "(inside the step its input was just written by the producing conv: partly "
                                               "L2 / Infinity-Cache resident; cold-HBM rate: profiles/, tools/gn_once.py)",
                     "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),

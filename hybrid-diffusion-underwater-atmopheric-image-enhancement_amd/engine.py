@@ -137,7 +137,6 @@ class Plan:
         self._graph_stream: Optional[torch.cuda.Stream] = None
         self.flops = 0.0          # algorithmic FLOPs of the MFMA-bound launches (convolutions, attention) of one run
         self._vec_jobs: List[tuple] = []          # per-block embedding projections, emitted as ONE launch (flush_block_vecs)
-        self._gn_counters: Optional[torch.Tensor] = None
 
     # -- memory -------------------------------------------------------------------------------------------------------
     def buf(self, *shape: int, dtype=torch.float32) -> torch.Tensor:
@@ -267,13 +266,10 @@ class Plan:
         nsplit = max(1, min(32, HW // 4096))     # a function of the plane size only: per-sample results must not depend on B
         ws = self.buf(B * GN_GROUPS * nsplit * 3)
         scale, shift = self.buf(B, Ct), self.buf(B, Ct)
-        # statistics and the (mean, rstd, gamma, beta) -> scale / shift fold in one launch: the last-arriving workgroup of a
-        # (sample, group) merges the partials; the arrival counters are shared by every GroupNorm of the plan (zero between launches)
-        if self._gn_counters is None or self._gn_counters.numel() < B * GN_GROUPS:
-            self._gn_counters = torch.zeros(B * GN_GROUPS, dtype=torch.int32, device=self.device)
+        # statistics and the (mean, rstd, gamma, beta) -> scale / shift fold behind one entry point: one launch when a
+        # (sample, group) is a single workgroup (planes up to 64x64), the streaming pass + the small merge kernel otherwise
         self.call("hdiff_gn_scale_shift", _ptr(x0), _ptr(x1), C0, C1, B, HW, GN_GROUPS, nsplit, ws.data_ptr(),
-                  self._gn_counters.data_ptr(), gamma.data_ptr(), beta.data_ptr(), C.c_float(GN_EPS), scale.data_ptr(),
-                  shift.data_ptr())
+                  gamma.data_ptr(), beta.data_ptr(), C.c_float(GN_EPS), scale.data_ptr(), shift.data_ptr())
         self.keep((x0, x1, gamma, beta, ws))
         self.free(ws)
         return scale, shift

@@ -146,12 +146,11 @@ int hdiff_gn_stats(const float* x0, const float* x1, int C0, int C1, int B, int 
 int hdiff_gn_finalize(const float* ws, int B, int C, int G, int nsplit, const float* gamma, const float* beta, float eps,
                       float* scale, float* shift, float* mean_out /*[B][G] or NULL*/, float* rstd_out /*[B][G] or NULL*/,
                       hdiff_stream_t stream);
-/* hdiff_gn_stats + hdiff_gn_finalize in ONE launch: the workgroup of a (sample, group) that finishes last merges the
- * partials and writes scale / shift (agent-scope release / acquire around a per-(sample, group) arrival counter).
- * counters: B*G uint32 in device memory, zero before the first use; every launch leaves them at zero again.  Results are
- * bit-identical to the two-launch form (same merge order). */
+/* hdiff_gn_stats + hdiff_gn_finalize behind one entry point.  nsplit == 1 (planes up to 64x64: every (sample, group) is
+ * one workgroup) -> ONE launch, the workgroup folds its own statistics into scale / shift; nsplit > 1 -> the streaming
+ * pass and the small merge kernel, as two launches of the same call.  Results are bit-identical to the two-call form. */
 int hdiff_gn_scale_shift(const float* x0, const float* x1, int C0, int C1, int B, int HW, int G, int nsplit, float* ws,
-                         uint32_t* counters, const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                         const float* gamma, const float* beta, float eps, float* scale, float* shift,
                          hdiff_stream_t stream);
 /* Backward of GroupNorm + Swish (the conv prologue): dA is the gradient w.r.t. the activated tensor [B][C0+C1][HW];
  * mean/rstd [B][G] come from hdiff_gn_finalize.  Writes dx0 [B][C0][HW], dx1 [B][C1][HW], dgamma [C], dbeta [C].

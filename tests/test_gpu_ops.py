@@ -129,8 +129,8 @@ def test_groupnorm_scale_shift(C0, C1, H, W, B):
 
 @pytest.mark.parametrize("C0,C1,HW,B", [(128, 0, 65536, 2), (256, 128, 16384, 3), (64, 0, 4096, 1), (32, 0, 100, 4)])
 def test_groupnorm_fused_finalize_equals_two_launches(C0, C1, HW, B):
-    """hdiff_gn_scale_shift (the last-arriving workgroup of a (sample, group) folds the partials) against hdiff_gn_stats +
-    hdiff_gn_finalize: the same bits, launch after launch on the same arrival counters (they wrap back to zero)."""
+    """hdiff_gn_scale_shift (one launch when a (sample, group) is one workgroup, else stats + merge inside the one call)
+    against hdiff_gn_stats + hdiff_gn_finalize: the same bits."""
     g = torch.Generator(device=DEV).manual_seed(C0 + HW)
     xa = torch.randn(B, C0, HW, device=DEV, generator=g) * 3 - 1
     xb = torch.randn(B, C1, HW, device=DEV, generator=g) + 2 if C1 else None
@@ -144,16 +144,13 @@ def test_groupnorm_fused_finalize_equals_two_launches(C0, C1, HW, B):
     _capi.check(lib.hdiff_gn_stats(px(xa), px(xb), C0, C1, B, HW, 32, nsplit, ws.data_ptr(), s))
     _capi.check(lib.hdiff_gn_finalize(ws.data_ptr(), B, Ct, 32, nsplit, gamma.data_ptr(), beta.data_ptr(), C.c_float(1e-5),
                                       sc0.data_ptr(), sh0.data_ptr(), None, None, s))
-    counters = torch.zeros(B * 32, dtype=torch.int32, device=DEV)
-    for rep in range(3):
+    for rep in range(2):
         ws2 = torch.full_like(ws, float("nan"))
         sc1, sh1 = torch.full_like(sc0, float("nan")), torch.full_like(sh0, float("nan"))
-        _capi.check(lib.hdiff_gn_scale_shift(px(xa), px(xb), C0, C1, B, HW, 32, nsplit, ws2.data_ptr(), counters.data_ptr(),
-                                             gamma.data_ptr(), beta.data_ptr(), C.c_float(1e-5), sc1.data_ptr(), sh1.data_ptr(),
-                                             s))
+        _capi.check(lib.hdiff_gn_scale_shift(px(xa), px(xb), C0, C1, B, HW, 32, nsplit, ws2.data_ptr(), gamma.data_ptr(),
+                                             beta.data_ptr(), C.c_float(1e-5), sc1.data_ptr(), sh1.data_ptr(), s))
         torch.cuda.synchronize()
         assert torch.equal(sc1, sc0) and torch.equal(sh1, sh0), rep
-        assert int(counters.abs().sum().item()) == 0
 
 
 def test_linear_rows_multi_equals_the_launches_it_replaces():
