@@ -201,7 +201,7 @@ def train_steps(size, batch, steps, warmup, dropout, dev, rank=0, world=1, rehea
     dt = parallel.max_over_ranks((time.perf_counter() - t0) / steps, None if rehearse else dev)
     fwd = FWD_GFLOP.get(size, FWD_GFLOP[64] * (size / 64) ** 2)
     res = {"size": size, "batch_per_gpu": batch, "n_gpus": world, "s_per_step": dt, "samples_per_s": world * batch / dt,
-           "fwd_equiv_tflops_per_gpu": 3 * fwd * batch / 1e3 / dt, "loss": float(loss), "grad_norm": float(gn),
+           "fwd_equiv_tflops_per_gpu": 3 * fwd * batch / 1e3 / dt, "loss": float(loss.detach()), "grad_norm": float(gn),
            "all_grads_present": all(p.grad is not None for p in weights),
            "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 1e9, "gradient_exchange_bytes_per_rank": exchanged,
            "dropout": dropout, "steps": steps, "warmup": warmup}
