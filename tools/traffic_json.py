@@ -17,7 +17,7 @@ import bench
 
 # key in the table            kernel-name filter         pass dirs prefix   wide loads   kernel sources
 ENTRIES = (
-    ("mha_flash_fwd_L65536_B16_bf16x3", "x3_kernel<16", "x3", True, ["attention_x3.hip", "attention_x3p.hip", "common.h"]),
+    ("mha_flash_fwd_L65536_B16_bf16x3", "mha_flash_fwd_x3_kernelILi16", "x3", True, ["attention_x3.hip", "attention_x3p.hip", "common.h"]),
     ("mha_flash_fwd_L65536_B16", "fast_kernel<16", "attn", True, ["attention.hip", "common.h"]),
     ("conv3x3_128_256_B16", "igemm_kernel<2, 8, 12, 5, 1", "conv", False, ["conv_igemm.hip", "common.h"]),
     ("gn_stats_128_256_B16", "gn_stats_kernel", "gn", True, ["groupnorm.hip", "common.h"]),
