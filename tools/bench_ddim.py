@@ -16,7 +16,7 @@ ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--ddim-step", type=int, default=100)
 ap.add_argument("--reps", type=int, default=2)
-ap.add_argument("--contract", choices=["f32", "bf16x3"], default="f32")
+ap.add_argument("--contract", choices=["f32", "bf16x3"], default="bf16x3", help="the library's default mode is bf16x3")
 a = ap.parse_args()
 hdiff_amd.set_contraction_mode(a.contract)
 dev = torch.device("cuda", 0)
