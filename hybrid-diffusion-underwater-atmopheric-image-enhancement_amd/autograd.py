@@ -45,11 +45,15 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 # launch helpers (immediate execution)
 # ----------------------------------------------------------------------------------------------------------------------
 def _run_conv(x0, x1, sources, taps: E.TapSet, cout: int, cin: int, bias, out, *, B, H, W, VH, VW, in_stride=1,
-              out_map=(1, 0, 1, 0), gn=None, addvec=None, residual=None) -> None:
+              out_map=(1, 0, 1, 0), gn=None, addvec=None, residual=None, x3=None) -> None:
+    """x3 = (forward weight [3x3], transposed?): also pack the split-bf16 copy, so that a plain 3x3 / stride-1 launch (the
+    forward conv, or its input-gradient conv on the transposed, mirrored weight) runs conv3x3_x3.hip in the bf16x3 mode."""
     plan = E.Plan(x0.device)
     pk = E.PackedConv(x0.device, cout, cin, taps)
     for (w, mode, ky, kx, acc) in sources:
         pk.add_source(w, mode, ky, kx, acc)
+    if x3 is not None and in_stride == 1 and out_map == (1, 0, 1, 0):
+        pk.enable_x3(x3[0], transposed=x3[1])
     plan.packs.append(pk)
     plan.conv(x0, x1, pk, bias, out, B=B, H=H, W=W, VH=VH, VW=VW, in_stride=in_stride, out_map=out_map, gn=gn,
               addvec=addvec, residual=residual)
@@ -156,7 +160,7 @@ class _FusedConv(Function):
         taps = E.conv_taps(k, pad)
         out = torch.empty(B, cout, H, W, device=dev)
         _run_conv(conv_in0, conv_in1, [(weight, 0, taps.ky, taps.kx, 0)], taps, cout, cin, bias, out, B=B, H=H, W=W, VH=H,
-                  VW=W, gn=conv_gn, addvec=addvec, residual=residual)
+                  VW=W, gn=conv_gn, addvec=addvec, residual=residual, x3=(weight, False) if k == 3 else None)
         ctx.k, ctx.has_x1, ctx.has_gn, ctx.dropped = k, x1 is not None, gn_w is not None, mask is not None
         ctx.has_bias, ctx.has_vec, ctx.has_res = bias is not None, addvec is not None, residual is not None
         saved = [x0, x1, weight, gn_w, gn_b, mean, rstd, gn[0] if gn else None, gn[1] if gn else None, mask,
@@ -199,7 +203,8 @@ class _FusedConv(Function):
             # as [pad - ky], and the order the specialised 3x3 kernels recognise
             dtaps = E.TapSet(taps.dy, taps.dx, [pad - dy for dy in taps.dy], [pad - dx for dx in taps.dx])
             dA = torch.empty(B, cin, H, W, device=dev)
-            _run_conv(dout, None, [(weight, 1, dtaps.ky, dtaps.kx, 0)], dtaps, cin, cout, None, dA, B=B, H=H, W=W, VH=H, VW=W)
+            _run_conv(dout, None, [(weight, 1, dtaps.ky, dtaps.kx, 0)], dtaps, cin, cout, None, dA, B=B, H=H, W=W, VH=H, VW=W,
+                      x3=(weight, True) if k == 3 else None)
             if ctx.dropped:
                 _capi.check(lib.hdiff_mul(dA.data_ptr(), mask.data_ptr(), dA.data_ptr(), dA.numel(), s), "mul")
             if ctx.has_gn:

@@ -216,9 +216,11 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   }
 }
 
-// fp32 [Cout][Cin][3][3] -> [Cin/16][tap][piece][CoutPad][8 words]: word j of a row = bf16 pieces of input channels 2j, 2j+1
+// fp32 [Cout][Cin][3][3] -> [Cin/16][tap][piece][CoutPad][8 words]: word j of a row = bf16 pieces of input channels 2j, 2j+1.
+// transposed: the source is [Cin][Cout][3][3] read with mirrored taps -- the weight of the INPUT-GRADIENT convolution
+// (W'[o][i][ky][kx] = w[i][o][2-ky][2-kx]: the dgrad of a 3x3 / stride-1 conv is the same conv on this weight).
 __global__ void pack_conv_weight_x3_kernel(const float* __restrict__ w, unsigned* __restrict__ wp3, int Cout, int Cin,
-                                           int CoutPad) {
+                                           int CoutPad, int transposed) {
   const size_t n = (size_t)(Cin / 16) * 9 * CoutPad * 8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int j = (int)(i % 8);
@@ -230,8 +232,13 @@ __global__ void pack_conv_weight_x3_kernel(const float* __restrict__ w, unsigned
     float a = 0.f, c = 0.f;
     if (co < Cout) {
       const int ci = chunk * 16 + 2 * j;
-      a = w[((size_t)co * Cin + ci) * 9 + tap];
-      c = w[((size_t)co * Cin + ci + 1) * 9 + tap];
+      if (transposed) {
+        a = w[((size_t)ci * Cout + co) * 9 + (8 - tap)];
+        c = w[((size_t)(ci + 1) * Cout + co) * 9 + (8 - tap)];
+      } else {
+        a = w[((size_t)co * Cin + ci) * 9 + tap];
+        c = w[((size_t)co * Cin + ci + 1) * 9 + tap];
+      }
     }
     unsigned h0, h1, h2;
     split3(a, c, h0, h1, h2);
@@ -255,7 +262,8 @@ void launch_conv3x3_x3(const ConvX3K& k, int B, hipStream_t stream) {
 
 }  // namespace hdiff
 
-extern "C" int hdiff_pack_conv_weight_x3(const float* w, void* wp3, int Cout, int Cin, int CoutPad, hdiff_stream_t stream) {
+extern "C" int hdiff_pack_conv_weight_x3(const float* w, void* wp3, int Cout, int Cin, int CoutPad, int transposed,
+                                         hdiff_stream_t stream) {
   HDIFF_CHECK_ARG(w && wp3, "pack_conv_weight_x3: null pointer");
   HDIFF_CHECK_ARG(Cout > 0 && Cin > 0 && Cin % 16 == 0 && CoutPad >= Cout && CoutPad % 64 == 0,
                   "pack_conv_weight_x3: needs Cin %% 16 == 0 and CoutPad %% 64 == 0 (Cin %d, Cout %d, CoutPad %d)", Cin, Cout, CoutPad);
@@ -263,7 +271,7 @@ extern "C" int hdiff_pack_conv_weight_x3(const float* w, void* wp3, int Cout, in
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
   hipLaunchKernelGGL(pack_conv_weight_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned*)wp3, Cout, Cin,
-                     CoutPad);
+                     CoutPad, transposed);
   HDIFF_CHECK_LAUNCH("pack_conv_weight_x3_kernel");
   return HDIFF_OK;
 }

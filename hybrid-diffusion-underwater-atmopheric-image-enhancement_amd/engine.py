@@ -92,12 +92,16 @@ class PackedConv:
         self.sources: List[Tuple[torch.Tensor, int, int, int, List[int], List[int], int]] = []
         self.wp3: Optional[torch.Tensor] = None      # split-bf16 copy (standard 3x3 convs with Cin % 16 == 0), see enable_x3
         self._x3_src: Optional[torch.Tensor] = None
+        self._x3_transposed = False
 
-    def enable_x3(self, w: torch.Tensor) -> None:
-        """Also keep the weights as three bf16 pieces (conv3x3_x3.hip) -- used when the contraction mode is bf16x3."""
+    def enable_x3(self, w: torch.Tensor, transposed: bool = False) -> None:
+        """Also keep the weights as three bf16 pieces (conv3x3_x3.hip) -- used when the contraction mode is bf16x3.
+        ``transposed``: ``w`` is the FORWARD conv's weight and this pack belongs to its input-gradient conv (same kernel on
+        the transposed, tap-mirrored weight: cout / cin of this pack are the forward's cin / cout)."""
         if self.ntaps == 9 and self.cin % 16 == 0 and tuple(w.shape[2:]) == (3, 3):
             self.wp3 = torch.empty((self.cin // 16) * 9 * 3 * self.cout_pad * 8, dtype=torch.int32, device=self.wp.device)
             self._x3_src = w
+            self._x3_transposed = bool(transposed)
 
     def add_source(self, w: torch.Tensor, mode: int, ky: Sequence[int], kx: Sequence[int], accumulate: int) -> None:
         kh, kw = int(w.shape[2]), int(w.shape[3])
@@ -114,7 +118,7 @@ class PackedConv:
                         "pack_conv_weight")
         if self.wp3 is not None:
             _capi.check(lib.hdiff_pack_conv_weight_x3(self._x3_src.data_ptr(), self.wp3.data_ptr(), self.cout, self.cin,
-                                                      self.cout_pad, stream), "pack_conv_weight_x3")
+                                                      self.cout_pad, int(self._x3_transposed), stream), "pack_conv_weight_x3")
 
 
 # ----------------------------------------------------------------------------------------------------------------------

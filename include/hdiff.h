@@ -64,8 +64,11 @@ int hdiff_pack_conv_weight(const float* w, float* wp, int mode, int Cout, int Ci
                            hdiff_stream_t stream);
 
 /* Weights of a standard 3x3 conv ([Cout][Cin][3][3], Cin % 16 == 0) as three bf16 pieces per value, laid out
- * [Cin/16][tap][piece][CoutPad][16] for conv3x3_x3.hip; wp3 holds (Cin/16)*9*3*CoutPad*8 32-bit words. */
-int hdiff_pack_conv_weight_x3(const float* w, void* wp3, int Cout, int Cin, int CoutPad, hdiff_stream_t stream);
+ * [Cin/16][tap][piece][CoutPad][16] for conv3x3_x3.hip; wp3 holds (Cin/16)*9*3*CoutPad*8 32-bit words.
+ * transposed != 0: w is [Cin][Cout][3][3] and is read with mirrored taps -- the weight of the input-gradient convolution
+ * of a 3x3 / stride-1 conv (Cout / Cin are those of the gradient conv: its outputs are the forward's inputs). */
+int hdiff_pack_conv_weight_x3(const float* w, void* wp3, int Cout, int Cin, int CoutPad, int transposed,
+                              hdiff_stream_t stream);
 
 typedef struct hdiff_conv_desc {
   /* input: virtual channel-concat of x0 [B][C0][H][W] and x1 [B][C1][H][W] (x1 may be NULL with C1 = 0);

@@ -373,3 +373,26 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     res = subprocess.run([os.sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True,
                          env=env, timeout=300)
     assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr and not res.stdout.strip()
+
+
+def test_roofline_traffic_table_is_stamped_and_goes_stale_with_the_kernel_sources(tmp_path, monkeypatch):
+    """profiles/roofline_traffic.json carries the commit it was measured at and a hash of each entry's kernel sources;
+    bench.load_traffic() reports an entry only while the sources still hash to that (a stale counter is not a measurement
+    of the run that prints it)."""
+    import bench
+    table, stamp = bench.load_traffic()
+    assert stamp.get("measured_at_commit") and stamp.get("measured_utc")
+    assert set(stamp["kernels"]) >= {"mha_flash_fwd_L65536_B16", "mha_flash_fwd_L65536_B16_bf16x3", "gn_stats_128_256_B16"}
+    for key, state in stamp["kernels"].items():
+        assert (state == "fresh") == (key in table), (key, state)
+    # a changed kernel source: its entries disappear from the table, the others stay
+    import shutil
+    fake = tmp_path / "csrc"
+    shutil.copytree(bench.CSRC, fake, ignore=shutil.ignore_patterns("build"))
+    with open(fake / "attention.hip", "a") as fh:
+        fh.write("// edited\n")
+    monkeypatch.setattr(bench, "CSRC", str(fake))
+    table2, stamp2 = bench.load_traffic()
+    assert "mha_flash_fwd_L65536_B16" not in table2 and stamp2["kernels"]["mha_flash_fwd_L65536_B16"].startswith("STALE")
+    if stamp["kernels"]["gn_stats_128_256_B16"] == "fresh":
+        assert "gn_stats_128_256_B16" in table2
