@@ -1,11 +1,12 @@
 """Dev tool: time every launch of one UNet forward plan on its own (HIP events around repeated launches) and print the conv
 launches by shape with their TFLOP/s.   python3 tools/plan_breakdown.py [size=256] [batch=16] [reps=5]"""
 import collections
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hdiff_amd  # noqa: F401
 from hdiff_amd.DiffusionFreeGuidence.ModelCondition import UNet
 
