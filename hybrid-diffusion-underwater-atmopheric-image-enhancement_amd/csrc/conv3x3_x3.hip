@@ -15,6 +15,8 @@
 //   * the weights are not staged: hdiff_pack_conv_weight_x3 lays them out as [chunk][tap][piece][channel][16 ci], so a lane's
 //     A operand is one 16-byte global load (L1/L2 resident: every workgroup of the launch reads the same 55 KB per chunk);
 //   * per tap 6 piece pairs x (2 x 2) tiles = 24 MFMAs; the next tap's weight loads are issued before them.
+#include <type_traits>
+
 #include "common.h"
 
 using namespace hdiff;
@@ -42,6 +44,8 @@ constexpr int THREADS = 256;
 constexpr int PH = 10, PW = 34, PPIX = PH * PW;      // patch of an 8 x 32 tile
 constexpr int NSLOT = (8 * PPIX + THREADS - 1) / THREADS;   // (channel pair, pixel) staging slots per thread: 11
 constexpr int PIECE_WORDS = PPIX * 8;                 // 32-bit words of one piece plane: [pixel][8 channel pairs]
+constexpr int PSTRIDE = PIECE_WORDS + 8;              // plane stride: each plane is followed by a dump area ...
+constexpr int DUMP_WORD = PIECE_WORDS;                // ... where the unused staging slot of a thread stores (branch-free staging)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -72,7 +76,7 @@ __device__ constexpr int TERM_W[6] = {2, 1, 0, 1, 0, 0};
 __device__ constexpr int TERM_X[6] = {0, 1, 2, 0, 1, 0};
 
 __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
-  __shared__ __attribute__((aligned(16))) unsigned sX[3 * PIECE_WORDS];
+  __shared__ __attribute__((aligned(16))) unsigned sX[3 * PSTRIDE];
   extern __shared__ __attribute__((aligned(16))) float sG[];     // [2][Cin]: GroupNorm scale | shift of this sample
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
     const int py = pos / PW, px = pos - py * PW;
     const int iy = vy0 - 1 + py, ix = vx0 - 1 + px;
     const bool used = j < 8;
-    s_pair[i] = j;
-    s_lds[i] = used ? pos * 8 + j : -1;
+    s_pair[i] = used ? j : 7;
+    s_lds[i] = used ? pos * 8 + j : DUMP_WORD;
     s_goff[i] = (used && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
   }
   if (has_gn) {
@@ -104,13 +108,17 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
       sG[i] = (i < p.Cin) ? p.gn_scale[b * p.Cin + i] : p.gn_shift[b * p.Cin + (i - p.Cin)];
   }
 
-  f32x16 acc[2][2];
+  // Wave tile: 32 output channels x 4 pixel rows (wm = channel half, wn = row half of the 64 x (8 x 32) workgroup tile).
+  // With all four waves on the same 64 channels (round 2: waves split the pixels only) every wave loaded the SAME weight
+  // operands: 24 KB per tap per workgroup through the CU's 64 B/clk vector L1 -- 62 B/clk with two workgroups per CU, and
+  // the PMC showed the waves parked on those loads 36 % of their time (MFMA busy 0.47).  The 2 x 2 split halves the
+  // weight traffic and doubles the LDS operand reads, of which there is bandwidth to spare.
+  const int wm = wave & 1, wn = wave >> 1;
+  f32x16 acc[4];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
   float xa[NSLOT], xb[NSLOT];
   auto issue_loads = [&](int c0) {
@@ -120,99 +128,145 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
     for (int i = 0; i < NSLOT; ++i) {
       const bool ok = s_goff[i] >= 0;
       const float* src = xbase + (size_t)(2 * s_pair[i]) * HW + (ok ? s_goff[i] : 0);
-      xa[i] = ok ? src[0] : 0.f;
-      xb[i] = ok ? src[HW] : 0.f;
+      const float va = src[0], vb = src[HW];       // unconditional (the address is always valid): no branch per slot
+      xa[i] = ok ? va : 0.f;
+      xb[i] = ok ? vb : 0.f;
     }
   };
-  auto store_staged = [&](int c0) {
+  // Branch-free: a slot outside the image stages 0 by a select, a thread's unused last slot writes to a dump word behind the
+  // piece planes -- with per-slot branches the GroupNorm table reads of a slot could not be issued before the previous slot
+  // had finished, and every slot paid an LDS round trip of its own (11 per chunk and wave).
+  auto store_staged = [&](auto gn_tag, int c0) {
+    constexpr bool GN = decltype(gn_tag)::value;
+    float sc0[NSLOT], sh0[NSLOT], sc1[NSLOT], sh1[NSLOT];
+    if (GN) {
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i) {
+        const int ci = c0 + 2 * s_pair[i];
+        sc0[i] = sG[ci]; sh0[i] = sG[p.Cin + ci];
+        sc1[i] = sG[ci + 1]; sh1[i] = sG[p.Cin + ci + 1];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
-      if (s_lds[i] >= 0) {
-        float a = xa[i], c = xb[i];
-        if (has_gn && s_goff[i] >= 0) {
-          const int ci = c0 + 2 * s_pair[i];
-          a = swish_fast(fmaf(a, sG[ci], sG[p.Cin + ci]));
-          c = swish_fast(fmaf(c, sG[ci + 1], sG[p.Cin + ci + 1]));
-        }
-        unsigned h0, h1, h2;
-        split3(a, c, h0, h1, h2);
-        sX[s_lds[i]] = h0;
-        sX[PIECE_WORDS + s_lds[i]] = h1;
-        sX[2 * PIECE_WORDS + s_lds[i]] = h2;
+      float a = xa[i], c = xb[i];
+      if (GN) {
+        const bool inside = s_goff[i] >= 0;
+        const float ga = swish_fast(fmaf(a, sc0[i], sh0[i])), gc = swish_fast(fmaf(c, sc1[i], sh1[i]));
+        a = inside ? ga : 0.f;
+        c = inside ? gc : 0.f;
       }
+      unsigned h0, h1, h2;
+      split3(a, c, h0, h1, h2);
+      sX[s_lds[i]] = h0;
+      sX[PSTRIDE + s_lds[i]] = h1;
+      sX[2 * PSTRIDE + s_lds[i]] = h2;
     }
   };
 
   // operand addresses: B = 8 channels (h picks the half) of pixel (row, l31) of this wave's N tile; A = 8 input channels of
   // output channel co0 + mt*32 + l31
-  int boff[2];
+  int boff[4];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) boff[nt] = ((wave * 2 + nt) * PW + l31) * 8 + h * 4;
-  const unsigned* wlane = p.wp3 + ((size_t)(co0 + l31) * 8 + h * 4);
+  for (int nt = 0; nt < 4; ++nt) boff[nt] = ((wn * 4 + nt) * PW + l31) * 8 + h * 4;
+  const unsigned* wlane = p.wp3 + ((size_t)(co0 + wm * 32 + l31) * 8 + h * 4);
   const size_t w_piece = (size_t)p.CoutPad * 8;            // words between pieces
   const size_t w_tap = 3 * w_piece, w_chunk = 9 * w_tap;
 
-  auto load_w = [&](u32x4 (&wa)[2][3], int chunk, int tap) {
+  auto load_w = [&](u32x4 (&wa)[3], int chunk, int tap) {
     const unsigned* wb = wlane + (size_t)chunk * w_chunk + (size_t)tap * w_tap;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) wa[mt][pc] = *reinterpret_cast<const u32x4*>(wb + pc * w_piece + mt * 32 * 8);
+    for (int pc = 0; pc < 3; ++pc) wa[pc] = *reinterpret_cast<const u32x4*>(wb + pc * w_piece);
   };
-  auto mma_tap = [&](const u32x4 (&wa)[2][3], int tap) {
+  // One unit = (tap, pixel row nt): 6 MFMAs on acc[nt].  The B operands of unit u + 1 are read from LDS at the start of unit
+  // u and the weights of tap + 2 are requested at the start of tap (two taps = 1 500 MFMA cycles ahead: an L2 hit under load
+  // takes about one tap), so that no unit starts by waiting for its own operands.
+  auto load_x = [&](u32x4 (&xp)[3], int tap, int nt) {
     const int toff = ((tap / 3) * PW + (tap % 3)) * 8;
-    u32x4 xp[2][3];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int pc = 0; pc < 3; ++pc) xp[pc] = *reinterpret_cast<const u32x4*>(&sX[pc * PSTRIDE + boff[nt] + toff]);
+  };
+  auto mma_unit = [&](const u32x4 (&wa)[3], const u32x4 (&xp)[3], int nt) {
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) xp[nt][pc] = *reinterpret_cast<const u32x4*>(&sX[pc * PIECE_WORDS + boff[nt] + toff]);
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(wa[mt][TERM_W[t]], xp[nt][TERM_X[t]], acc[mt][nt]);
+    for (int t = 0; t < 6; ++t) acc[nt] = mfma_bf16(wa[TERM_W[t]], xp[TERM_X[t]], acc[nt]);
   };
 
   const int nchunks = p.Cin / 16;
   issue_loads(0);
   __syncthreads();     // sG visible
   for (int c = 0; c < nchunks; ++c) {
-    store_staged(c * 16);
+    if (has_gn) store_staged(std::true_type{}, c * 16);
+    else store_staged(std::false_type{}, c * 16);
     __syncthreads();
     if (c + 1 < nchunks) issue_loads((c + 1) * 16);
-    u32x4 wA[2][3], wB[2][3];
-    load_w(wA, c, 0);
+    u32x4 w[3][3], xp[2][3];
+    load_w(w[0], c, 0);
+    load_w(w[1], c, 1);
+    load_x(xp[0], 0, 0);
 #pragma unroll
-    for (int tap = 0; tap < 9; tap += 2) {
-      if (tap + 1 < 9) load_w(wB, c, tap + 1);
-      mma_tap(wA, tap);
-      if (tap + 2 < 9) load_w(wA, c, tap + 2);
-      if (tap + 1 < 9) mma_tap(wB, tap + 1);
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 2 < 9) load_w(w[(tap + 2) % 3], c, tap + 2);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int u = tap * 4 + nt;
+        if (u + 1 < 36) load_x(xp[(u + 1) & 1], (u + 1) / 4, (u + 1) % 4);
+        mma_unit(w[tap % 3], xp[u & 1], nt);
+      }
     }
     __syncthreads();
   }
 
-  // ---- epilogue: + bias + per-sample channel vector + residual, NCHW store (32 consecutive pixels per register row)
+  // ---- epilogue: + bias + per-sample channel vector + residual, NCHW store (32 consecutive pixels per register row).
+  // A full tile (workgroup-uniform test: everything but edge tiles and a channel tail) takes the branch-free form: the 16
+  // bias / vector values of the lane's channels are fetched together, then per pixel row all 16 residual loads are in
+  // flight before the first add -- with per-element tests every output waited for its own three loads in turn (64 dependent
+  // round trips per lane: a quarter of the kernel's time at 128 channels).
+  if (co0 + 64 <= p.Cout && vy0 + 8 <= p.H && vx0 + 32 <= p.W) {
+    float add[16];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int vy = vy0 + wave * 2 + nt, vx = vx0 + l31;
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float a = 0.f;
+      if (p.bias) a += p.bias[co];
+      if (p.addvec) a += p.addvec[b * p.Cout + co];
+      add[r] = a;
+    }
+    const size_t lane_base = ((size_t)b * p.Cout + co0 + wm * 32 + 4 * h) * HW + (size_t)(vy0 + wn * 4) * p.W + vx0 + l31;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const size_t row = lane_base + (size_t)nt * p.W;
+      float res[16];
+      if (p.residual) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[r] = p.residual[row + (size_t)((r & 3) + 8 * (r >> 2)) * HW];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[nt][r] + add[r];
+        if (p.residual) v += res[r];
+        p.out[row + (size_t)((r & 3) + 8 * (r >> 2)) * HW] = v;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int vy = vy0 + wn * 4 + nt, vx = vx0 + l31;
     if (vy >= p.H || vx >= p.W) continue;
     const size_t pix = (size_t)vy * p.W + vx;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < p.Cout) {
-          float v = acc[mt][nt][r];
-          if (p.bias) v += p.bias[co];
-          if (p.addvec) v += p.addvec[b * p.Cout + co];
-          const size_t o = ((size_t)b * p.Cout + co) * HW + pix;
-          if (p.residual) v += p.residual[o];
-          p.out[o] = v;
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (co < p.Cout) {
+        float a = 0.f;                               // the same order of additions as the full-tile form
+        if (p.bias) a += p.bias[co];
+        if (p.addvec) a += p.addvec[b * p.Cout + co];
+        float v = acc[nt][r] + a;
+        const size_t o = ((size_t)b * p.Cout + co) * HW + pix;
+        if (p.residual) v += p.residual[o];
+        p.out[o] = v;
       }
+    }
   }
 }
 
