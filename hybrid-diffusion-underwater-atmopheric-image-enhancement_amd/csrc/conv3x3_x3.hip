@@ -76,7 +76,7 @@ __device__ constexpr int TERM_W[6] = {2, 1, 0, 1, 0, 0};
 __device__ constexpr int TERM_X[6] = {0, 1, 2, 0, 1, 0};
 
 __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
-  __shared__ __attribute__((aligned(16))) unsigned sX[3 * PSTRIDE];
+  __shared__ __attribute__((aligned(16))) unsigned sXbuf[2][3 * PSTRIDE];     // double-buffered: chunk c + 1 is staged beside chunk c's MFMAs
   extern __shared__ __attribute__((aligned(16))) float sG[];     // [2][Cin]: GroupNorm scale | shift of this sample
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -136,32 +136,25 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   // Branch-free: a slot outside the image stages 0 by a select, a thread's unused last slot writes to a dump word behind the
   // piece planes -- with per-slot branches the GroupNorm table reads of a slot could not be issued before the previous slot
   // had finished, and every slot paid an LDS round trip of its own (11 per chunk and wave).
-  auto store_staged = [&](auto gn_tag, int c0) {
+  auto stage_slot = [&](auto gn_tag, int i, int c0, unsigned* sX) {
     constexpr bool GN = decltype(gn_tag)::value;
-    float sc0[NSLOT], sh0[NSLOT], sc1[NSLOT], sh1[NSLOT];
+    float a = xa[i], c = xb[i];
     if (GN) {
-#pragma unroll
-      for (int i = 0; i < NSLOT; ++i) {
-        const int ci = c0 + 2 * s_pair[i];
-        sc0[i] = sG[ci]; sh0[i] = sG[p.Cin + ci];
-        sc1[i] = sG[ci + 1]; sh1[i] = sG[p.Cin + ci + 1];
-      }
+      const int ci = c0 + 2 * s_pair[i];
+      const bool inside = s_goff[i] >= 0;
+      const float ga = swish_fast(fmaf(a, sG[ci], sG[p.Cin + ci])), gc = swish_fast(fmaf(c, sG[ci + 1], sG[p.Cin + ci + 1]));
+      a = inside ? ga : 0.f;
+      c = inside ? gc : 0.f;
     }
+    unsigned h0, h1, h2;
+    split3(a, c, h0, h1, h2);
+    sX[s_lds[i]] = h0;
+    sX[PSTRIDE + s_lds[i]] = h1;
+    sX[2 * PSTRIDE + s_lds[i]] = h2;
+  };
+  auto store_staged = [&](auto gn_tag, int c0, unsigned* sX) {
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-      float a = xa[i], c = xb[i];
-      if (GN) {
-        const bool inside = s_goff[i] >= 0;
-        const float ga = swish_fast(fmaf(a, sc0[i], sh0[i])), gc = swish_fast(fmaf(c, sc1[i], sh1[i]));
-        a = inside ? ga : 0.f;
-        c = inside ? gc : 0.f;
-      }
-      unsigned h0, h1, h2;
-      split3(a, c, h0, h1, h2);
-      sX[s_lds[i]] = h0;
-      sX[PSTRIDE + s_lds[i]] = h1;
-      sX[2 * PSTRIDE + s_lds[i]] = h2;
-    }
+    for (int i = 0; i < NSLOT; ++i) stage_slot(gn_tag, i, c0, sX);
   };
 
   // operand addresses: B = 8 channels (h picks the half) of pixel (row, l31) of this wave's N tile; A = 8 input channels of
@@ -181,7 +174,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   // One unit = (tap, pixel row nt): 6 MFMAs on acc[nt].  The B operands of unit u + 1 are read from LDS at the start of unit
   // u and the weights of tap + 2 are requested at the start of tap (two taps = 1 500 MFMA cycles ahead: an L2 hit under load
   // takes about one tap), so that no unit starts by waiting for its own operands.
-  auto load_x = [&](u32x4 (&xp)[3], int tap, int nt) {
+  auto load_x = [&](u32x4 (&xp)[3], const unsigned* sX, int tap, int nt) {
     const int toff = ((tap / 3) * PW + (tap % 3)) * 8;
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) xp[pc] = *reinterpret_cast<const u32x4*>(&sX[pc * PSTRIDE + boff[nt] + toff]);
@@ -191,29 +184,48 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
     for (int t = 0; t < 6; ++t) acc[nt] = mfma_bf16(wa[TERM_W[t]], xp[TERM_X[t]], acc[nt]);
   };
 
-  const int nchunks = p.Cin / 16;
-  issue_loads(0);
-  __syncthreads();     // sG visible
-  for (int c = 0; c < nchunks; ++c) {
-    if (has_gn) store_staged(std::true_type{}, c * 16);
-    else store_staged(std::false_type{}, c * 16);
-    __syncthreads();
-    if (c + 1 < nchunks) issue_loads((c + 1) * 16);
+  // Chunk loop, ONE barrier per chunk: while the matrix core works through chunk c (LDS buffer c & 1), the vector pipe turns
+  // the raw patch of chunk c + 1 (in registers since the previous chunk) into split pieces in the other buffer, one or two
+  // staging slots behind every tap's MFMAs; the global loads of chunk c + 2 leave once those registers are free.
+  auto chunk = [&](auto gn_tag, auto more_tag, int c, int nchunks) {
+    constexpr bool more = decltype(more_tag)::value;      // compile time: the staging must not sit in a block of its own
+    const unsigned* sX = sXbuf[c & 1];
+    unsigned* sNext = sXbuf[(c + 1) & 1];
     u32x4 w[3][3], xp[2][3];
     load_w(w[0], c, 0);
     load_w(w[1], c, 1);
-    load_x(xp[0], 0, 0);
+    load_x(xp[0], sX, 0, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       if (tap + 2 < 9) load_w(w[(tap + 2) % 3], c, tap + 2);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int u = tap * 4 + nt;
-        if (u + 1 < 36) load_x(xp[(u + 1) & 1], (u + 1) / 4, (u + 1) % 4);
+        if (u + 1 < 36) load_x(xp[(u + 1) & 1], sX, (u + 1) / 4, (u + 1) % 4);
         mma_unit(w[tap % 3], xp[u & 1], nt);
       }
+      if (more) {
+        stage_slot(gn_tag, tap, (c + 1) * 16, sNext);
+        if (tap + 9 < NSLOT) stage_slot(gn_tag, tap + 9, (c + 1) * 16, sNext);
+      }
     }
+    if (c + 2 < nchunks) issue_loads((c + 2) * 16);
     __syncthreads();
+  };
+
+  const int nchunks = p.Cin / 16;
+  issue_loads(0);
+  __syncthreads();     // sG visible
+  if (has_gn) store_staged(std::true_type{}, 0, sXbuf[0]);
+  else store_staged(std::false_type{}, 0, sXbuf[0]);
+  if (nchunks > 1) issue_loads(16);
+  __syncthreads();
+  if (has_gn) {
+    for (int c = 0; c + 1 < nchunks; ++c) chunk(std::true_type{}, std::true_type{}, c, nchunks);
+    chunk(std::true_type{}, std::false_type{}, nchunks - 1, nchunks);
+  } else {
+    for (int c = 0; c + 1 < nchunks; ++c) chunk(std::false_type{}, std::true_type{}, c, nchunks);
+    chunk(std::false_type{}, std::false_type{}, nchunks - 1, nchunks);
   }
 
   // ---- epilogue: + bias + per-sample channel vector + residual, NCHW store (32 consecutive pixels per register row).
