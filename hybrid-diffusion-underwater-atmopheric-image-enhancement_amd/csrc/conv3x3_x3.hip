@@ -42,8 +42,9 @@ namespace {
 
 constexpr int THREADS = 256;
 constexpr int PH = 10, PW = 34, PPIX = PH * PW;      // patch of an 8 x 32 tile
-constexpr int NSLOT = (8 * PPIX + THREADS - 1) / THREADS;   // (channel pair, pixel) staging slots per thread: 11
-constexpr int PIECE_WORDS = PPIX * 8;                 // 32-bit words of one piece plane: [pixel][8 channel pairs]
+constexpr int NSLOT = (4 * PPIX + THREADS - 1) / THREADS;   // (channel quad, pixel) staging slots per thread: 6
+constexpr int HALF_WORDS = PPIX * 4;                  // one half-plane: [pixel][4 words] = channel pairs 4h .. 4h+3 of every pixel
+constexpr int PIECE_WORDS = 2 * HALF_WORDS;           // 32-bit words of one piece: [half h][pixel][4 channel pairs]
 constexpr int PSTRIDE = PIECE_WORDS + 8;              // plane stride: each plane is followed by a dump area ...
 constexpr int DUMP_WORD = PIECE_WORDS;                // ... where the unused staging slot of a thread stores (branch-free staging)
 
@@ -88,19 +89,23 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   const bool has_gn = p.gn_scale != nullptr;
   const size_t HW = (size_t)p.H * p.W;
 
-  // staging slots: slot e = (channel pair j = e / 340, patch pixel e % 340)
+  // LDS layout of a piece: two half-planes [h][pixel][4 words]; word w of half h holds the bf16 pieces of input channels
+  // 8h + 2w, 8h + 2w + 1.  A lane's B operand (8 channels of one pixel) is ONE 16-byte read and consecutive lanes read
+  // consecutive 16-byte blocks: conflict-free.  (Round 2's [pixel][8 words] put lanes 8 words apart: the operand reads were
+  // 2-way and the 4-byte staging stores 8-way bank-conflicted -- SQ_LDS_BANK_CONFLICT was 60 % of the LDS-active cycles.)
+  // staging slots: slot e = (channel quad jq = e / 340: channels 4 jq .. 4 jq + 3, patch pixel e % 340); 8-byte stores
   int s_goff[NSLOT];      // iy * W + ix of the pixel, or -1 (zero padding / unused slot)
-  int s_lds[NSLOT];       // word offset inside a piece plane, or -1 (unused slot)
-  int s_pair[NSLOT];
+  int s_lds[NSLOT];       // word offset inside a piece, or the dump word (unused slot)
+  int s_quad[NSLOT];
 #pragma unroll
   for (int i = 0; i < NSLOT; ++i) {
     const int e = tid + i * THREADS;
-    const int j = e / PPIX, pos = e - j * PPIX;
+    const int jq = e / PPIX, pos = e - jq * PPIX;
     const int py = pos / PW, px = pos - py * PW;
     const int iy = vy0 - 1 + py, ix = vx0 - 1 + px;
-    const bool used = j < 8;
-    s_pair[i] = used ? j : 7;
-    s_lds[i] = used ? pos * 8 + j : DUMP_WORD;
+    const bool used = jq < 4;
+    s_quad[i] = used ? jq : 3;
+    s_lds[i] = used ? (jq >> 1) * HALF_WORDS + pos * 4 + (jq & 1) * 2 : DUMP_WORD;
     s_goff[i] = (used && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
   }
   if (has_gn) {
@@ -120,17 +125,16 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-  float xa[NSLOT], xb[NSLOT];
+  f32x4 xv[NSLOT];
   auto issue_loads = [&](int c0) {
     // a 16-channel chunk never straddles the concat seam (C0 % 16 == 0 is checked on the host)
     const float* xbase = (c0 < p.C0) ? p.x0 + ((size_t)b * p.C0 + c0) * HW : p.x1 + ((size_t)b * p.C1 + (c0 - p.C0)) * HW;
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
       const bool ok = s_goff[i] >= 0;
-      const float* src = xbase + (size_t)(2 * s_pair[i]) * HW + (ok ? s_goff[i] : 0);
-      const float va = src[0], vb = src[HW];       // unconditional (the address is always valid): no branch per slot
-      xa[i] = ok ? va : 0.f;
-      xb[i] = ok ? vb : 0.f;
+      const float* src = xbase + (size_t)(4 * s_quad[i]) * HW + (ok ? s_goff[i] : 0);
+      const float v0 = src[0], v1 = src[HW], v2 = src[2 * HW], v3 = src[3 * HW];   // unconditional: the address is always valid
+      xv[i] = f32x4{ok ? v0 : 0.f, ok ? v1 : 0.f, ok ? v2 : 0.f, ok ? v3 : 0.f};
     }
   };
   // Branch-free: a slot outside the image stages 0 by a select, a thread's unused last slot writes to a dump word behind the
@@ -138,19 +142,25 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   // had finished, and every slot paid an LDS round trip of its own (11 per chunk and wave).
   auto stage_slot = [&](auto gn_tag, int i, int c0, unsigned* sX) {
     constexpr bool GN = decltype(gn_tag)::value;
-    float a = xa[i], c = xb[i];
+    f32x4 v = xv[i];
     if (GN) {
-      const int ci = c0 + 2 * s_pair[i];
+      const int ci = c0 + 4 * s_quad[i];
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(&sG[ci]);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(&sG[p.Cin + ci]);
       const bool inside = s_goff[i] >= 0;
-      const float ga = swish_fast(fmaf(a, sG[ci], sG[p.Cin + ci])), gc = swish_fast(fmaf(c, sG[ci + 1], sG[p.Cin + ci + 1]));
-      a = inside ? ga : 0.f;
-      c = inside ? gc : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gk = swish_fast(fmaf(v[k], sc[k], sh[k]));
+        v[k] = inside ? gk : 0.f;
+      }
     }
-    unsigned h0, h1, h2;
-    split3(a, c, h0, h1, h2);
-    sX[s_lds[i]] = h0;
-    sX[PSTRIDE + s_lds[i]] = h1;
-    sX[2 * PSTRIDE + s_lds[i]] = h2;
+    unsigned a0, a1, a2, c0w, c1w, c2w;
+    split3(v[0], v[1], a0, a1, a2);
+    split3(v[2], v[3], c0w, c1w, c2w);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2*>(&sX[s_lds[i]]) = u32x2{a0, c0w};
+    *reinterpret_cast<u32x2*>(&sX[PSTRIDE + s_lds[i]]) = u32x2{a1, c1w};
+    *reinterpret_cast<u32x2*>(&sX[2 * PSTRIDE + s_lds[i]]) = u32x2{a2, c2w};
   };
   auto store_staged = [&](auto gn_tag, int c0, unsigned* sX) {
 #pragma unroll
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   // output channel co0 + mt*32 + l31
   int boff[4];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) boff[nt] = ((wn * 4 + nt) * PW + l31) * 8 + h * 4;
+  for (int nt = 0; nt < 4; ++nt) boff[nt] = h * HALF_WORDS + ((wn * 4 + nt) * PW + l31) * 4;
   const unsigned* wlane = p.wp3 + ((size_t)(co0 + wm * 32 + l31) * 8 + h * 4);
   const size_t w_piece = (size_t)p.CoutPad * 8;            // words between pieces
   const size_t w_tap = 3 * w_piece, w_chunk = 9 * w_tap;
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   // u and the weights of tap + 2 are requested at the start of tap (two taps = 1 500 MFMA cycles ahead: an L2 hit under load
   // takes about one tap), so that no unit starts by waiting for its own operands.
   auto load_x = [&](u32x4 (&xp)[3], const unsigned* sX, int tap, int nt) {
-    const int toff = ((tap / 3) * PW + (tap % 3)) * 8;
+    const int toff = ((tap / 3) * PW + (tap % 3)) * 4;
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) xp[pc] = *reinterpret_cast<const u32x4*>(&sX[pc * PSTRIDE + boff[nt] + toff]);
   };
@@ -204,10 +214,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
         if (u + 1 < 36) load_x(xp[(u + 1) & 1], sX, (u + 1) / 4, (u + 1) % 4);
         mma_unit(w[tap % 3], xp[u & 1], nt);
       }
-      if (more) {
-        stage_slot(gn_tag, tap, (c + 1) * 16, sNext);
-        if (tap + 9 < NSLOT) stage_slot(gn_tag, tap + 9, (c + 1) * 16, sNext);
-      }
+      if (more && tap < NSLOT) stage_slot(gn_tag, tap, (c + 1) * 16, sNext);
     }
     if (c + 2 < nchunks) issue_loads((c + 2) * 16);
     __syncthreads();
