@@ -1,10 +1,13 @@
 """Dev tool: launch the dominant attention kernel a few times at the bench shape (for rocprofv3 --pmc passes).
-argv: [batch] ; the contraction mode comes from HDIFF_CONTRACT (bf16x3: the pre-split kernel, with its workspace)."""
+argv: [batch] [channels = 128] [L = 65536]; the contraction mode comes from HDIFF_CONTRACT (default bf16x3: the pre-split
+kernels, with their workspace)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch, hdiff_amd
 lib = hdiff_amd.lib()
-B, Cc, L = int(sys.argv[1]) if len(sys.argv) > 1 else 16, 128, 65536
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+Cc = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 qkv = torch.randn(B, 3 * Cc, L, device="cuda")
 o = torch.empty(B, Cc, L, device="cuda")
 need = C.c_int64(0)
