@@ -28,7 +28,8 @@ Rank 0 prints ONE JSON line with the contract keys plus
   cpu_baseline  the CPU oracle (oracle/cpu_path.py, kind "port"): one whole UNet forward at 128x128 timed on the host
                 cores (a bounded sample), scaled to the benchmark's step by the algorithmic FLOP ratio; ``same_config``
                 holds the one BASELINE config the CPU finishes in full (C1), timed on both sides
-  parity        max-abs / PSNR of the HIP path against the oracle on the inputs the two legs above computed anyway
+  parity        max-abs / PSNR of the HIP path against the oracle on the inputs the two legs above computed anyway, and
+                `modes`: the sampler state of the full-size workload after the same steps in the two contraction modes
   configs       the other BASELINE configs on this GPU (N = 1 only; never part of ``value``): C1 in full, C2 20 steps,
                 C5 one step of one GPU's share, C3 one optimizer step (``--no-extras`` skips them)
 """
@@ -465,6 +466,7 @@ def main():
         elapsed = time.perf_counter() - t0
         assert int(sp.nan_flag.item()) == 0, "nan in tensor."
         assert int(sp.step.item()) == MODEL["T"] - 1 - (K + Wm)
+        x_timed = sp.x.clone()                         # the state after Wm + K steps in the timed mode (for `parity.modes`)
 
         # second pass: the same steps (same start state, same time steps) as plain launches with HIP events around the
         # launches of interest; the warm-up steps are replayed so that the K instrumented steps are the K timed ones
@@ -483,12 +485,14 @@ def main():
 
         # the other contraction mode, reported beside the headline (never part of `value`)
         alt = None
+        mode_parity = None
         if world == 1 and not a.no_alt:
             other = "bf16x3" if a.contract == "f32" else "f32"
             hdiff_amd.set_contraction_mode(other)
             use_graph = False                         # a captured graph bakes the contraction mode: plain launches here
             reset()
-            one_step()
+            for _ in range(Wm):                       # the same Wm + K steps (same x_T, same Philox noise) as the timed pass
+                one_step()
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for _ in range(K):
@@ -497,6 +501,11 @@ def main():
             dt_alt = (time.perf_counter() - t1) / K
             hdiff_amd.set_contraction_mode(a.contract)
             assert int(sp.nan_flag.item()) == 0, "nan in tensor."
+            diff = (sp.x.double() - x_timed.double()).abs()
+            mode_parity = {"what": f"pre-clip sampler state after {Wm + K} denoising steps of the benchmark workload ({S}x{S}, batch "
+                                   f"{B}, same x_T and in-kernel noise) in the two contraction modes, {a.contract} vs {other}",
+                           "max_abs": diff.max().item(), "rms": diff.pow(2).mean().sqrt().item(),
+                           "state_abs_max": x_timed.abs().max().item(), "state_rms": x_timed.double().pow(2).mean().sqrt().item()}
             alt = {"contract": other, "ms_per_step": dt_alt * 1e3, "denoising_steps_per_s": 1.0 / dt_alt,
                    "note": "same workload with the attention / 3x3-conv contractions in the other mode (plain launches); "
                            "f32 = fp32-input MFMA (exact k-ordered fma chain); bf16x3 = every fp32 operand as three bf16 "
@@ -590,11 +599,13 @@ def main():
         }
     # everything below is outside the timed region and never enters `value`; N = 1 only
     if rank == 0 and world == 1:
-        del plan, sp, sampler, model
+        del plan, sp, sampler, model, x_timed
         _release()
         if not a.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(S, B, dev)
             _release()
+        if mode_parity is not None:
+            out.setdefault("parity", {})["modes"] = mode_parity
         if not a.no_extras:
             try:
                 out["configs"] = other_configs(dev, small=a.extras_scale == "small")

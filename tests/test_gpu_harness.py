@@ -72,6 +72,7 @@ def test_bench_json_contract_small():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["same_config"]["cpu_steps_per_s"] > 0
     par = d["parity"]
     assert par["max_abs"] <= par["tolerance_max_abs"], par
+    assert par["modes"]["max_abs"] <= 1e-3 * max(1.0, par["modes"]["state_abs_max"]), par["modes"]     # the two contraction modes agree at the benchmark's own size
     assert par["end_to_end_C1"]["psnr_db"] >= 40.0
     cfgs = d["configs"]
     assert "error" not in cfgs, cfgs
