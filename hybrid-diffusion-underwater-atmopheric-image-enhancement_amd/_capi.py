@@ -65,6 +65,8 @@ _PROTOS = {
     "hdiff_last_error": (C.c_char_p, []),
     "hdiff_device_count": (C.c_int, []),
     "hdiff_pack_conv_weight_x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hdiff_pack_conv_weight_x3_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p]),
     "hdiff_set_contraction_mode": (C.c_int, [C.c_int]),
     "hdiff_get_contraction_mode": (C.c_int, []),
     "hdiff_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -75,6 +75,27 @@ bool wgrad1x1_applicable(const hdiff_conv_wgrad_desc* d);     // same file: the 
 int wgrad1x1_nsplit(const hdiff_conv_wgrad_desc* d);
 int launch_wgrad1x1(const hdiff_conv_wgrad_desc* d, float* dwp, int nsplit, hipStream_t stream);
 
+// conv3x3_x3.hip: split-bf16 convolution over the 3x3 neighbourhood (plain 3x3 / stride-1 convs and the four output-parity
+// phases of the transposed 5x5 / stride-2 conv: every tap offset lies in [-1, 1]^2)
+struct ConvX3K {
+  const float* x0;
+  const float* x1;
+  int C0, C1, Cin, H, W;
+  const unsigned* wp3;             // [Cin/16][ntaps][3][CoutPad][8] packed bf16 pairs
+  int CoutPad, Cout;
+  const float* bias;
+  const float* gn_scale;
+  const float* gn_shift;
+  const float* addvec;
+  const float* residual;
+  float* out;
+  int tiles_x;
+  int ntaps;                       // 9, 6 or 4
+  int tap_off[9];                  // LDS word offset of the tap inside the staged patch: ((dy + 1) * 34 + (dx + 1)) * 4
+  int OH, OW, out_sy, out_oy, out_sx, out_ox;     // output pixel (vy * out_sy + out_oy, vx * out_sx + out_ox) of an OH x OW plane
+};
+void launch_conv3x3_x3(const ConvX3K& k, int B, hipStream_t stream);
+
 int contraction_mode();   // HDIFF_CONTRACT_*
 // attention_x3.hip: returns false when the shape is not covered (caller falls back to the fp32 kernels)
 // attention_x3p.hip: the same contraction on operands split ONCE into a workspace (0 bytes = shape not covered)

@@ -21,23 +21,6 @@
 
 using namespace hdiff;
 
-namespace hdiff {
-struct ConvX3K {
-  const float* x0;
-  const float* x1;
-  int C0, C1, Cin, H, W;
-  const unsigned* wp3;             // [Cin/16][9][3][CoutPad][8] packed bf16 pairs
-  int CoutPad, Cout;
-  const float* bias;
-  const float* gn_scale;
-  const float* gn_shift;
-  const float* addvec;
-  const float* residual;
-  float* out;
-  int tiles_x;
-};
-}  // namespace hdiff
-
 namespace {
 
 constexpr int THREADS = 256;
@@ -76,6 +59,9 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 __device__ constexpr int TERM_W[6] = {2, 1, 0, 1, 0, 0};
 __device__ constexpr int TERM_X[6] = {0, 1, 2, 0, 1, 0};
 
+// NT: taps of the launch (9 = the 3x3 conv, 6 / 4 = transposed-conv phases with fewer taps); OUTMAP: the output pixel of
+// (vy, vx) is (vy * out_sy + out_oy, vx * out_sx + out_ox) of an OH x OW plane (transposed-conv phases) instead of (vy, vx).
+template <int NT, bool OUTMAP>
 __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   __shared__ __attribute__((aligned(16))) unsigned sXbuf[2][3 * PSTRIDE];     // double-buffered: chunk c + 1 is staged beside chunk c's MFMAs
   extern __shared__ __attribute__((aligned(16))) float sG[];     // [2][Cin]: GroupNorm scale | shift of this sample
@@ -174,7 +160,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   for (int nt = 0; nt < 4; ++nt) boff[nt] = h * HALF_WORDS + ((wn * 4 + nt) * PW + l31) * 4;
   const unsigned* wlane = p.wp3 + ((size_t)(co0 + wm * 32 + l31) * 8 + h * 4);
   const size_t w_piece = (size_t)p.CoutPad * 8;            // words between pieces
-  const size_t w_tap = 3 * w_piece, w_chunk = 9 * w_tap;
+  const size_t w_tap = 3 * w_piece, w_chunk = NT * w_tap;
 
   auto load_w = [&](u32x4 (&wa)[3], int chunk, int tap) {
     const unsigned* wb = wlane + (size_t)chunk * w_chunk + (size_t)tap * w_tap;
@@ -185,7 +171,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   // u and the weights of tap + 2 are requested at the start of tap (two taps = 1 500 MFMA cycles ahead: an L2 hit under load
   // takes about one tap), so that no unit starts by waiting for its own operands.
   auto load_x = [&](u32x4 (&xp)[3], const unsigned* sX, int tap, int nt) {
-    const int toff = ((tap / 3) * PW + (tap % 3)) * 4;
+    const int toff = p.tap_off[tap];                    // ((dy + 1) * PW + (dx + 1)) * 4, wave-uniform
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) xp[pc] = *reinterpret_cast<const u32x4*>(&sX[pc * PSTRIDE + boff[nt] + toff]);
   };
@@ -206,15 +192,19 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
     load_w(w[1], c, 1);
     load_x(xp[0], sX, 0, 0);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      if (tap + 2 < 9) load_w(w[(tap + 2) % 3], c, tap + 2);
+    for (int tap = 0; tap < NT; ++tap) {
+      if (tap + 2 < NT) load_w(w[(tap + 2) % 3], c, tap + 2);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int u = tap * 4 + nt;
-        if (u + 1 < 36) load_x(xp[(u + 1) & 1], sX, (u + 1) / 4, (u + 1) % 4);
+        if (u + 1 < 4 * NT) load_x(xp[(u + 1) & 1], sX, (u + 1) / 4, (u + 1) % 4);
         mma_unit(w[tap % 3], xp[u & 1], nt);
       }
       if (more && tap < NSLOT) stage_slot(gn_tag, tap, (c + 1) * 16, sNext);
+    }
+    if (more) {
+#pragma unroll
+      for (int i = NT; i < NSLOT; ++i) stage_slot(gn_tag, i, (c + 1) * 16, sNext);     // fewer taps than staging slots
     }
     if (c + 2 < nchunks) issue_loads((c + 2) * 16);
     __syncthreads();
@@ -240,6 +230,9 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   // bias / vector values of the lane's channels are fetched together, then per pixel row all 16 residual loads are in
   // flight before the first add -- with per-element tests every output waited for its own three loads in turn (64 dependent
   // round trips per lane: a quarter of the kernel's time at 128 channels).
+  const size_t OHW = OUTMAP ? (size_t)p.OH * p.OW : HW;
+  const int osy = OUTMAP ? p.out_sy : 1, ooy = OUTMAP ? p.out_oy : 0, osx = OUTMAP ? p.out_sx : 1, oox = OUTMAP ? p.out_ox : 0;
+  const int OW = OUTMAP ? p.OW : p.W;
   if (co0 + 64 <= p.Cout && vy0 + 8 <= p.H && vx0 + 32 <= p.W) {
     float add[16];
 #pragma unroll
@@ -250,20 +243,21 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
       if (p.addvec) a += p.addvec[b * p.Cout + co];
       add[r] = a;
     }
-    const size_t lane_base = ((size_t)b * p.Cout + co0 + wm * 32 + 4 * h) * HW + (size_t)(vy0 + wn * 4) * p.W + vx0 + l31;
+    const size_t lane_base = ((size_t)b * p.Cout + co0 + wm * 32 + 4 * h) * OHW +
+                             (size_t)((vy0 + wn * 4) * osy + ooy) * OW + (size_t)(vx0 + l31) * osx + oox;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      const size_t row = lane_base + (size_t)nt * p.W;
+      const size_t row = lane_base + (size_t)(nt * osy) * OW;
       float res[16];
       if (p.residual) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) res[r] = p.residual[row + (size_t)((r & 3) + 8 * (r >> 2)) * HW];
+        for (int r = 0; r < 16; ++r) res[r] = p.residual[row + (size_t)((r & 3) + 8 * (r >> 2)) * OHW];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[nt][r] + add[r];
         if (p.residual) v += res[r];
-        p.out[row + (size_t)((r & 3) + 8 * (r >> 2)) * HW] = v;
+        p.out[row + (size_t)((r & 3) + 8 * (r >> 2)) * OHW] = v;
       }
     }
     return;
@@ -272,7 +266,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   for (int nt = 0; nt < 4; ++nt) {
     const int vy = vy0 + wn * 4 + nt, vx = vx0 + l31;
     if (vy >= p.H || vx >= p.W) continue;
-    const size_t pix = (size_t)vy * p.W + vx;
+    const size_t pix = (size_t)(vy * osy + ooy) * OW + (size_t)vx * osx + oox;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -281,7 +275,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
         if (p.bias) a += p.bias[co];
         if (p.addvec) a += p.addvec[b * p.Cout + co];
         float v = acc[nt][r] + a;
-        const size_t o = ((size_t)b * p.Cout + co) * HW + pix;
+        const size_t o = ((size_t)b * p.Cout + co) * OHW + pix;
         if (p.residual) v += p.residual[o];
         p.out[o] = v;
       }
@@ -289,36 +283,40 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   }
 }
 
-// fp32 [Cout][Cin][3][3] -> [Cin/16][tap][piece][CoutPad][8 words]: word j of a row = bf16 pieces of input channels 2j, 2j+1.
-// transposed: the source is [Cin][Cout][3][3] read with mirrored taps -- the weight of the INPUT-GRADIENT convolution
-// (W'[o][i][ky][kx] = w[i][o][2-ky][2-kx]: the dgrad of a 3x3 / stride-1 conv is the same conv on this weight).
-__global__ void pack_conv_weight_x3_kernel(const float* __restrict__ w, unsigned* __restrict__ wp3, int Cout, int Cin,
-                                           int CoutPad, int transposed) {
-  const size_t n = (size_t)(Cin / 16) * 9 * CoutPad * 8;
+// fp32 weights -> [Cin/16][tap][piece][CoutPad][8 words]: word j of a row = bf16 pieces of input channels 2j, 2j+1.  Tap t
+// reads kernel element (ky[t], kx[t]) of a KH x KW kernel stored [Cout][Cin][KH][KW] (mode 0) or [Cin][Cout][KH][KW] (mode 1:
+// nn.ConvTranspose2d's layout, and the layout of a forward weight seen from its input-gradient convolution).
+struct PackX3K {
+  int mode, Cout, Cin, KH, KW, ntaps, CoutPad;
+  int ky[9], kx[9];
+};
+__global__ void pack_conv_weight_x3_kernel(const float* __restrict__ w, unsigned* __restrict__ wp3, const PackX3K q) {
+  const size_t n = (size_t)(q.Cin / 16) * q.ntaps * q.CoutPad * 8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int j = (int)(i % 8);
     size_t r = i / 8;
-    const int co = (int)(r % CoutPad);
-    r /= CoutPad;
-    const int tap = (int)(r % 9);
-    const int chunk = (int)(r / 9);
+    const int co = (int)(r % q.CoutPad);
+    r /= q.CoutPad;
+    const int tap = (int)(r % q.ntaps);
+    const int chunk = (int)(r / q.ntaps);
     float a = 0.f, c = 0.f;
-    if (co < Cout) {
+    if (co < q.Cout) {
       const int ci = chunk * 16 + 2 * j;
-      if (transposed) {
-        a = w[((size_t)ci * Cout + co) * 9 + (8 - tap)];
-        c = w[((size_t)(ci + 1) * Cout + co) * 9 + (8 - tap)];
+      const size_t k = (size_t)q.ky[tap] * q.KW + q.kx[tap], kk = (size_t)q.KH * q.KW;
+      if (q.mode == 1) {
+        a = w[((size_t)ci * q.Cout + co) * kk + k];
+        c = w[((size_t)(ci + 1) * q.Cout + co) * kk + k];
       } else {
-        a = w[((size_t)co * Cin + ci) * 9 + tap];
-        c = w[((size_t)co * Cin + ci + 1) * 9 + tap];
+        a = w[((size_t)co * q.Cin + ci) * kk + k];
+        c = w[((size_t)co * q.Cin + ci + 1) * kk + k];
       }
     }
     unsigned h0, h1, h2;
     split3(a, c, h0, h1, h2);
-    const size_t base = ((size_t)(chunk * 9 + tap) * 3) * CoutPad * 8 + (size_t)co * 8 + j;
+    const size_t base = ((size_t)(chunk * q.ntaps + tap) * 3) * q.CoutPad * 8 + (size_t)co * 8 + j;
     wp3[base] = h0;
-    wp3[base + (size_t)CoutPad * 8] = h1;
-    wp3[base + 2 * (size_t)CoutPad * 8] = h2;
+    wp3[base + (size_t)q.CoutPad * 8] = h1;
+    wp3[base + 2 * (size_t)q.CoutPad * 8] = h2;
   }
 }
 
@@ -330,21 +328,50 @@ void launch_conv3x3_x3(const ConvX3K& k, int B, hipStream_t stream) {
   const int tiles_y = cdiv(k.H, 8);
   dim3 grid(k.tiles_x * tiles_y, cdiv(k.Cout, 64), B);
   const size_t dyn = (size_t)2 * k.Cin * sizeof(float);
-  hipLaunchKernelGGL(conv3x3_x3_kernel, grid, dim3(THREADS), dyn, stream, k);
+  const bool outmap = !(k.out_sy == 1 && k.out_oy == 0 && k.out_sx == 1 && k.out_ox == 0 && k.OH == k.H && k.OW == k.W);
+  if (k.ntaps == 9 && !outmap) hipLaunchKernelGGL((conv3x3_x3_kernel<9, false>), grid, dim3(THREADS), dyn, stream, k);
+  else if (k.ntaps == 9) hipLaunchKernelGGL((conv3x3_x3_kernel<9, true>), grid, dim3(THREADS), dyn, stream, k);
+  else if (k.ntaps == 6) hipLaunchKernelGGL((conv3x3_x3_kernel<6, true>), grid, dim3(THREADS), dyn, stream, k);
+  else hipLaunchKernelGGL((conv3x3_x3_kernel<4, true>), grid, dim3(THREADS), dyn, stream, k);
 }
 
 }  // namespace hdiff
+
+static int pack_x3(const float* w, void* wp3, int mode, int Cout, int Cin, int KH, int KW, int ntaps, const int* ky, const int* kx,
+                   int CoutPad, hipStream_t stream) {
+  PackX3K q{};
+  q.mode = mode; q.Cout = Cout; q.Cin = Cin; q.KH = KH; q.KW = KW; q.ntaps = ntaps; q.CoutPad = CoutPad;
+  for (int t = 0; t < ntaps; ++t) { q.ky[t] = ky[t]; q.kx[t] = kx[t]; }
+  const size_t n = (size_t)(Cin / 16) * ntaps * CoutPad * 8;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(pack_conv_weight_x3_kernel, dim3(blocks), dim3(256), 0, stream, w, (unsigned*)wp3, q);
+  HDIFF_CHECK_LAUNCH("pack_conv_weight_x3_kernel");
+  return HDIFF_OK;
+}
 
 extern "C" int hdiff_pack_conv_weight_x3(const float* w, void* wp3, int Cout, int Cin, int CoutPad, int transposed,
                                          hdiff_stream_t stream) {
   HDIFF_CHECK_ARG(w && wp3, "pack_conv_weight_x3: null pointer");
   HDIFF_CHECK_ARG(Cout > 0 && Cin > 0 && Cin % 16 == 0 && CoutPad >= Cout && CoutPad % 64 == 0,
                   "pack_conv_weight_x3: needs Cin %% 16 == 0 and CoutPad %% 64 == 0 (Cin %d, Cout %d, CoutPad %d)", Cin, Cout, CoutPad);
-  const size_t n = (size_t)(Cin / 16) * 9 * CoutPad * 8;
-  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  hipLaunchKernelGGL(pack_conv_weight_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned*)wp3, Cout, Cin,
-                     CoutPad, transposed);
-  HDIFF_CHECK_LAUNCH("pack_conv_weight_x3_kernel");
-  return HDIFF_OK;
+  int ky[9], kx[9];
+  for (int t = 0; t < 9; ++t) {                 // the input-gradient conv reads the forward weight transposed and tap-mirrored
+    ky[t] = transposed ? 2 - t / 3 : t / 3;
+    kx[t] = transposed ? 2 - t % 3 : t % 3;
+  }
+  return pack_x3(w, wp3, transposed ? 1 : 0, Cout, Cin, 3, 3, 9, ky, kx, CoutPad, (hipStream_t)stream);
+}
+
+extern "C" int hdiff_pack_conv_weight_x3_taps(const float* w, void* wp3, int mode, int Cout, int Cin, int KH, int KW, int ntaps,
+                                              const int* tap_ky, const int* tap_kx, int CoutPad, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(w && wp3 && tap_ky && tap_kx, "pack_conv_weight_x3_taps: null pointer");
+  HDIFF_CHECK_ARG(Cout > 0 && Cin > 0 && Cin % 16 == 0 && CoutPad >= Cout && CoutPad % 64 == 0 && (mode == 0 || mode == 1),
+                  "pack_conv_weight_x3_taps: needs Cin %% 16 == 0, CoutPad %% 64 == 0, mode 0 / 1 (Cin %d, Cout %d, CoutPad %d, mode %d)",
+                  Cin, Cout, CoutPad, mode);
+  HDIFF_CHECK_ARG(ntaps >= 1 && ntaps <= 9 && KH > 0 && KW > 0, "pack_conv_weight_x3_taps: ntaps %d out of range", ntaps);
+  for (int t = 0; t < ntaps; ++t)
+    HDIFF_CHECK_ARG(tap_ky[t] >= 0 && tap_ky[t] < KH && tap_kx[t] >= 0 && tap_kx[t] < KW,
+                    "pack_conv_weight_x3_taps: tap %d reads kernel element (%d, %d) of a %d x %d kernel", t, tap_ky[t], tap_kx[t], KH, KW);
+  return pack_x3(w, wp3, mode, Cout, Cin, KH, KW, ntaps, tap_ky, tap_kx, CoutPad, (hipStream_t)stream);
 }

@@ -601,14 +601,14 @@ int configure(const hdiff_conv_desc* d, ConvCfg& c) {
 
 }  // namespace
 
-namespace { bool is_direct_1x1(const hdiff_conv_desc* d); bool is_x3_3x3(const hdiff_conv_desc* d); }
+namespace { bool is_direct_1x1(const hdiff_conv_desc* d); bool is_x3_conv(const hdiff_conv_desc* d); }
 
 extern "C" int hdiff_conv2d_fwd_workspace(const hdiff_conv_desc* d, int64_t* floats_out) {
   HDIFF_CHECK_ARG(floats_out, "conv2d_fwd_workspace: null pointer");
   ConvCfg c;
   const int rc = configure(d, c);
   if (rc != HDIFF_OK) return rc;
-  *floats_out = (is_direct_1x1(d) || is_x3_3x3(d)) ? 0 : c.splitk_floats;
+  *floats_out = (is_direct_1x1(d) || is_x3_conv(d)) ? 0 : c.splitk_floats;
   return HDIFF_OK;
 }
 
@@ -628,33 +628,21 @@ struct Conv1x1K {
 void launch_conv1x1_direct(const Conv1x1K& k, int B, hipStream_t stream);   // conv1x1_direct.hip
 }  // namespace hdiff
 
-namespace hdiff {
-struct ConvX3K {
-  const float* x0;
-  const float* x1;
-  int C0, C1, Cin, H, W;
-  const unsigned* wp3;
-  int CoutPad, Cout;
-  const float* bias;
-  const float* gn_scale;
-  const float* gn_shift;
-  const float* addvec;
-  const float* residual;
-  float* out;
-  int tiles_x;
-};
-void launch_conv3x3_x3(const ConvX3K& k, int B, hipStream_t stream);          // conv3x3_x3.hip
-}  // namespace hdiff
-
 namespace {
-// Split-bf16 mode: a plain 3x3 / stride-1 / pad-1 conv with 16-channel-aligned inputs and a launch large enough to fill the
-// chip (small ones keep the split-K path of the fp32 kernel).
-bool is_x3_3x3(const hdiff_conv_desc* d) {
+// Split-bf16 mode: a stride-1 conv whose taps all lie in the 3x3 neighbourhood -- the plain 3x3 / pad-1 conv (9 taps, output
+// grid = input grid) and the output-parity phases of ConvTranspose2d(5, stride 2) (9 / 6 / 6 / 4 taps, output pixel
+// (2y + py, 2x + px)) -- with 16-channel-aligned inputs and a launch large enough to fill the chip (small ones keep the
+// split-K path of the fp32 kernel).
+bool is_x3_conv(const hdiff_conv_desc* d) {
   if (d->wp_x3 == nullptr || hdiff::contraction_mode() != HDIFF_CONTRACT_BF16X3) return false;
-  if (d->ntaps != 9 || d->in_stride != 1 || d->out_sy != 1 || d->out_oy != 0 || d->out_sx != 1 || d->out_ox != 0) return false;
-  if (d->VH != d->H || d->VW != d->W || d->OH != d->H || d->OW != d->W) return false;
-  for (int t = 0; t < 9; ++t)
-    if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1) return false;
+  if ((d->ntaps != 9 && d->ntaps != 6 && d->ntaps != 4) || d->in_stride != 1) return false;
+  if (d->VH != d->H || d->VW != d->W) return false;
+  const bool same = d->out_sy == 1 && d->out_oy == 0 && d->out_sx == 1 && d->out_ox == 0 && d->OH == d->H && d->OW == d->W;
+  const bool phase = d->out_sy == 2 && d->out_sx == 2 && (d->out_oy == 0 || d->out_oy == 1) && (d->out_ox == 0 || d->out_ox == 1) &&
+                     d->OH == 2 * d->H && d->OW == 2 * d->W && d->residual == nullptr;
+  if (!same && !phase) return false;
+  for (int t = 0; t < d->ntaps; ++t)
+    if (d->tap_dy[t] < -1 || d->tap_dy[t] > 1 || d->tap_dx[t] < -1 || d->tap_dx[t] > 1) return false;
   const int Cin = d->C0 + d->C1;
   if (Cin % 16 != 0 || (d->C1 != 0 && d->C0 % 16 != 0) || Cin > 4096) return false;
   const long blocks = (long)cdiv(d->W, 32) * cdiv(d->H, 8) * cdiv(d->Cout, 64) * d->B;
@@ -676,9 +664,14 @@ extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream)
   const int rc = configure(d, c);
   if (rc != HDIFF_OK) return rc;
   ConvK& k = c.k;
-  if (is_x3_3x3(d)) {
-    hdiff::ConvX3K q{d->x0, d->x1, d->C0, d->C1, d->C0 + d->C1, d->H, d->W, (const unsigned*)d->wp_x3, d->CoutPad, d->Cout,
-                     d->bias, d->gn_scale, d->gn_shift, d->addvec, d->residual, d->out, cdiv(d->W, 32)};
+  if (is_x3_conv(d)) {
+    hdiff::ConvX3K q{};
+    q.x0 = d->x0; q.x1 = d->x1; q.C0 = d->C0; q.C1 = d->C1; q.Cin = d->C0 + d->C1; q.H = d->H; q.W = d->W;
+    q.wp3 = (const unsigned*)d->wp_x3; q.CoutPad = d->CoutPad; q.Cout = d->Cout;
+    q.bias = d->bias; q.gn_scale = d->gn_scale; q.gn_shift = d->gn_shift; q.addvec = d->addvec; q.residual = d->residual;
+    q.out = d->out; q.tiles_x = cdiv(d->W, 32); q.ntaps = d->ntaps;
+    for (int t = 0; t < d->ntaps; ++t) q.tap_off[t] = ((d->tap_dy[t] + 1) * 34 + (d->tap_dx[t] + 1)) * 4;
+    q.OH = d->OH; q.OW = d->OW; q.out_sy = d->out_sy; q.out_oy = d->out_oy; q.out_sx = d->out_sx; q.out_ox = d->out_ox;
     (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
     hdiff::launch_conv3x3_x3(q, d->B, (hipStream_t)stream);
     HDIFF_CHECK_LAUNCH("conv3x3_x3_kernel");

@@ -93,6 +93,7 @@ class PackedConv:
         self.wp3: Optional[torch.Tensor] = None      # split-bf16 copy (standard 3x3 convs with Cin % 16 == 0), see enable_x3
         self._x3_src: Optional[torch.Tensor] = None
         self._x3_transposed = False
+        self._x3_taps: Optional[Tuple[int, int, int]] = None
 
     def enable_x3(self, w: torch.Tensor, transposed: bool = False) -> None:
         """Also keep the weights as three bf16 pieces (conv3x3_x3.hip) -- used when the contraction mode is bf16x3.
@@ -102,6 +103,15 @@ class PackedConv:
             self.wp3 = torch.empty((self.cin // 16) * 9 * 3 * self.cout_pad * 8, dtype=torch.int32, device=self.wp.device)
             self._x3_src = w
             self._x3_transposed = bool(transposed)
+            self._x3_taps = None
+
+    def enable_x3_taps(self, w: torch.Tensor, mode: int) -> None:
+        """The split-bf16 copy for a launch whose taps are a subset of the 3x3 neighbourhood reading elements (ky, kx) of a
+        larger kernel: the output-parity phases of ConvTranspose2d(5, stride 2) (mode 1 = its [Cin][Cout][5][5] layout)."""
+        if self.ntaps in (4, 6, 9) and self.cin % 16 == 0 and all(-1 <= v <= 1 for v in self.taps.dy + self.taps.dx):
+            self.wp3 = torch.empty((self.cin // 16) * self.ntaps * 3 * self.cout_pad * 8, dtype=torch.int32, device=self.wp.device)
+            self._x3_src = w
+            self._x3_taps = (int(mode), int(w.shape[2]), int(w.shape[3]))
 
     def add_source(self, w: torch.Tensor, mode: int, ky: Sequence[int], kx: Sequence[int], accumulate: int) -> None:
         kh, kw = int(w.shape[2]), int(w.shape[3])
@@ -116,7 +126,13 @@ class PackedConv:
             _capi.check(lib.hdiff_pack_conv_weight(w.data_ptr(), self.wp.data_ptr(), mode, self.cout, self.cin, kh, kw,
                                                    self.ntaps, a_ky, a_kx, self.cin_pad, self.cout_pad, acc, stream),
                         "pack_conv_weight")
-        if self.wp3 is not None:
+        if self.wp3 is not None and self._x3_taps is not None:
+            mode, kh, kw = self._x3_taps
+            a_ky, a_kx = (C.c_int * self.ntaps)(*self.taps.ky), (C.c_int * self.ntaps)(*self.taps.kx)
+            _capi.check(lib.hdiff_pack_conv_weight_x3_taps(self._x3_src.data_ptr(), self.wp3.data_ptr(), mode, self.cout, self.cin,
+                                                           kh, kw, self.ntaps, a_ky, a_kx, self.cout_pad, stream),
+                        "pack_conv_weight_x3_taps")
+        elif self.wp3 is not None:
             _capi.check(lib.hdiff_pack_conv_weight_x3(self._x3_src.data_ptr(), self.wp3.data_ptr(), self.cout, self.cin,
                                                       self.cout_pad, int(self._x3_transposed), stream), "pack_conv_weight_x3")
 
@@ -475,6 +491,7 @@ def emit_upsample(plan: Plan, P: Dict[str, torch.Tensor], p: str, x: torch.Tenso
             taps = tconv_phase_taps(py, px)
             pk = _new_pack(plan, Cc, Cc, taps)
             pk.add_source(wt, 1, taps.ky, taps.kx, 0)
+            pk.enable_x3_taps(wt, 1)             # every phase's taps lie in the 3x3 neighbourhood: the split-bf16 kernel serves them
             plan.conv(x, None, pk, P[f"{p}.t.bias"], u, B=B, H=H, W=W, VH=H, VW=W, out_map=(2, py, 2, px))
     pkc = _std_pack(plan, P[f"{p}.c.weight"], 3, 1)
     y = plan.buf(B, Cc, 2 * H, 2 * W)

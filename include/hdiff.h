@@ -69,6 +69,12 @@ int hdiff_pack_conv_weight(const float* w, float* wp, int mode, int Cout, int Ci
  * of a 3x3 / stride-1 conv (Cout / Cin are those of the gradient conv: its outputs are the forward's inputs). */
 int hdiff_pack_conv_weight_x3(const float* w, void* wp3, int Cout, int Cin, int CoutPad, int transposed,
                               hdiff_stream_t stream);
+/* The same pack for any launch of the split-bf16 convolution kernel (taps within the 3x3 neighbourhood): tap t reads kernel
+ * element (tap_ky[t], tap_kx[t]) of a KH x KW kernel stored [Cout][Cin][KH][KW] (mode 0) or [Cin][Cout][KH][KW] (mode 1,
+ * nn.ConvTranspose2d) -- the four output-parity phases of ConvTranspose2d(5, stride 2) are packed this way (9 / 6 / 6 / 4 taps);
+ * wp3 holds (Cin/16)*ntaps*3*CoutPad*8 32-bit words. */
+int hdiff_pack_conv_weight_x3_taps(const float* w, void* wp3, int mode, int Cout, int Cin, int KH, int KW, int ntaps,
+                                   const int* tap_ky, const int* tap_kx, int CoutPad, hdiff_stream_t stream);
 
 typedef struct hdiff_conv_desc {
   /* input: virtual channel-concat of x0 [B][C0][H][W] and x1 [B][C1][H][W] (x1 may be NULL with C1 = 0);
@@ -102,7 +108,8 @@ typedef struct hdiff_conv_desc {
   float* splitk_ws;
   int64_t splitk_floats;
   /* optional (ABI 2): the same weights as three bf16 pieces (hdiff_pack_conv_weight_x3).  Used instead of wp when the
-   * contraction mode is HDIFF_CONTRACT_BF16X3 and the launch is a plain 3x3 / stride-1 / pad-1 conv with Cin % 16 == 0;
+   * contraction mode is HDIFF_CONTRACT_BF16X3 and the launch is a stride-1 conv with Cin % 16 == 0 whose taps lie in the 3x3
+   * neighbourhood (the plain 3x3 / pad-1 conv; a transposed-conv phase with its (2, py, 2, px) output map);
    * NULL = always the fp32-input MFMA */
   const void* wp_x3;
 } hdiff_conv_desc;
