@@ -530,3 +530,36 @@ print("X3P16_OK", err, err_b)
     env = dict(os.environ, HDIFF_X3P="1")
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0 and "X3P16_OK" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("Cc,H,W,B", [(64, 64, 64, 8), (128, 32, 96, 4)])
+def test_upsample_phases_on_the_split_bf16_kernel(Cc, H, W, B, bf16x3_mode):
+    """UpSample.forward (ModelCondition.py:85-89): ConvTranspose2d(C, C, 5, 2, 2, 1) as four output-parity phases + Conv3x3.
+    At these sizes every phase launch is large enough for the split-bf16 kernel (tap lists + output map, conv3x3_x3.hip):
+    it must differ from the fp32-mode result (another program ran) and be fp32-class against float64."""
+    lib = bf16x3_mode
+    g = torch.Generator().manual_seed(Cc + H)
+    x = torch.randn(B, Cc, H, W, generator=g)
+    P = {"u.t.weight": torch.randn(Cc, Cc, 5, 5, generator=g) / math.sqrt(Cc * 6.25), "u.t.bias": torch.randn(Cc, generator=g),
+         "u.c.weight": torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(Cc * 9), "u.c.bias": torch.randn(Cc, generator=g)}
+    Pd = {k: v.to(DEV) for k, v in P.items()}
+    xd = x.to(DEV)
+
+    def run():
+        plan = E.Plan(DEV)
+        y = E.emit_upsample(plan, Pd, "u", xd, B, Cc, H, W)
+        plan.pack_weights()
+        plan.run()
+        torch.cuda.synchronize()
+        return y.clone()
+
+    got_x3 = run()
+    _capi.check(lib.hdiff_set_contraction_mode(0))
+    got_f32 = run()
+    _capi.check(lib.hdiff_set_contraction_mode(1))
+    assert not torch.equal(got_x3, got_f32), "the split-bf16 kernel did not run"
+    u = F.conv_transpose2d(x.double(), P["u.t.weight"].double(), P["u.t.bias"].double(), stride=2, padding=2, output_padding=1)
+    want = F.conv2d(u, P["u.c.weight"].double(), P["u.c.bias"].double(), padding=1)
+    close(got_x3, want.float(), rel=1e-5, what="upsample split-bf16")
+    rms = lambda t: (t.double().cpu() - want).pow(2).mean().sqrt().item()
+    assert rms(got_x3) <= 1.5 * rms(got_f32) + 1e-12, (rms(got_x3), rms(got_f32))
