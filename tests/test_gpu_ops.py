@@ -532,7 +532,7 @@ print("X3P16_OK", err, err_b)
     assert res.returncode == 0 and "X3P16_OK" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
 
 
-@pytest.mark.parametrize("Cc,H,W,B", [(64, 64, 64, 8), (128, 32, 96, 4)])
+@pytest.mark.parametrize("Cc,H,W,B", [(64, 64, 64, 16), (128, 32, 96, 8)])      # >= 192 workgroups per phase launch
 def test_upsample_phases_on_the_split_bf16_kernel(Cc, H, W, B, bf16x3_mode):
     """UpSample.forward (ModelCondition.py:85-89): ConvTranspose2d(C, C, 5, 2, 2, 1) as four output-parity phases + Conv3x3.
     At these sizes every phase launch is large enough for the split-bf16 kernel (tap lists + output map, conv3x3_x3.hip):
