@@ -517,6 +517,17 @@ void launch_fused(const BwdArgs& a, const BwdGeom& g, int B, int heads, hipStrea
 template <int D>
 int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* lse2, float* delta, float* dqkv, float* ws,
                int B, int C, int heads, int L, hipStream_t stream) {
+  if constexpr (D == 16) {
+    if (mha_bwd_x3_applicable(C, heads, L)) {       // bf16x3 mode: all five products on the bf16 matrix core
+      HDIFF_CHECK_ARG(ws != nullptr, "mha_flash_bwd: this shape needs a workspace (hdiff_mha_flash_bwd_workspace)");
+      const int total = B * heads * L;
+      (void)hipGetLastError();
+      hipLaunchKernelGGL(mha_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, o, d_o, delta, C, D, L, total);
+      launch_mha_bwd_x3(qkv, d_o, lse2, delta, dqkv, ws, B, C, heads, L, stream);
+      HDIFF_CHECK_LAUNCH("mha_bwd (split-bf16) kernels");
+      return HDIFF_OK;
+    }
+  }
   const BwdGeom g = bwd_geometry(B, heads, L, D);
   HDIFF_CHECK_ARG(g.nsplit == 1 || ws != nullptr, "mha_flash_bwd: this shape needs a workspace (hdiff_mha_flash_bwd_workspace)");
   BwdArgs a;
@@ -556,6 +567,10 @@ extern "C" int hdiff_mha_flash_bwd_workspace(int B, int C, int heads, int L, int
   HDIFF_CHECK_ARG(n_floats, "mha_flash_bwd_workspace: null pointer");
   HDIFF_CHECK_ARG(B > 0 && L > 0 && heads > 0 && C % heads == 0, "mha_flash_bwd_workspace: bad sizes B=%d C=%d heads=%d L=%d",
                   B, C, heads, L);
+  if (C / heads == 16 && mha_bwd_x3_applicable(C, heads, L)) {
+    *n_floats = mha_bwd_x3_workspace_floats(B, C, heads, L);
+    return HDIFF_OK;
+  }
   const BwdGeom g = bwd_geometry(B, heads, L, C / heads);
   *n_floats = (g.nsplit > 1) ? (int64_t)g.nsplit * B * C * L : 0;
   return HDIFF_OK;

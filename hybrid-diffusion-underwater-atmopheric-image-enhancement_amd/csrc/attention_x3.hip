@@ -56,6 +56,22 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& h0, unsigned&
   h2 = pack_hi16(sa, sb);
 }
 
+// one v_add_f32 the vectoriser cannot pair into v_pk_add_f32 (which stalls against the bf16 MFMA stream like the other
+// packed-fp32 forms: tools/valu_rates.hip -- 2.5 cycles for the plain add, 4.6 + a stall for the packed one)
+__device__ __forceinline__ float add1(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// the same for operands that come straight out of v_exp_f32: gfx950 forwards a transcendental result to the next vector
+// instruction only after one wait state, and the compiler's hazard pass does not look inside inline asm -- without the
+// s_nop the add reads garbage (found the hard way: tests/test_gpu_ops.py::test_flash_attention_core)
+__device__ __forceinline__ float add1_after_trans(float a, float b) {
+  float r;
+  asm("s_nop 0\n\tv_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -292,8 +308,8 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3_kernel(const floa
       for (int kt = 0; kt < 4; ++kt) {
         const f32x2 pa = {__builtin_amdgcn_exp2f(Sq[kt][0]), __builtin_amdgcn_exp2f(Sq[kt][1])};
         const f32x2 pc = {__builtin_amdgcn_exp2f(Sq[kt][2]), __builtin_amdgcn_exp2f(Sq[kt][3])};
-        sum0 += pa[0] + pc[0];      // scalar adds on purpose (see split3)
-        sum1 += pa[1] + pc[1];
+        sum0 = add1(sum0, add1_after_trans(pa[0], pc[0]));      // scalar adds on purpose (see add1)
+        sum1 = add1(sum1, add1_after_trans(pa[1], pc[1]));
         const int c = kt >> 1, o = (kt & 1) * 2;
         unsigned a0, a1, a2, c0, c1, c2;
         split3(pa[0], pa[1], a0, a1, a2);
@@ -301,8 +317,8 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3_kernel(const floa
         pop[qt & 1][0][c][o] = a0; pop[qt & 1][1][c][o] = a1; pop[qt & 1][2][c][o] = a2;
         pop[qt & 1][0][c][o + 1] = c0; pop[qt & 1][1][c][o + 1] = c1; pop[qt & 1][2][c][o + 1] = c2;
       }
-      l_run[qt][0] += sum0;
-      l_run[qt][1] += sum1;
+      l_run[qt][0] = add1(l_run[qt][0], sum0);
+      l_run[qt][1] = add1(l_run[qt][1], sum1);
     };
     qk(0);
     auto stage = [&](auto qt_tag) {

@@ -14,7 +14,15 @@ need = C.c_int64(0)
 lib.hdiff_mha_flash_fwd_workspace(B, Cc, 8, L, C.byref(need))
 ws = torch.empty(need.value // 4 + 1, device="cuda") if need.value > 0 else None
 s = torch.cuda.current_stream().cuda_stream
-for _ in range(3):
+def go():
     lib.hdiff_mha_flash_fwd_ws(qkv.data_ptr(), o.data_ptr(), None, B, Cc, 8, L, None if ws is None else ws.data_ptr(), need.value, s)
+go()
 torch.cuda.synchronize()
-print("done")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(3):
+    go()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 3
+print(f"fwd B={B} C={Cc} L={L}: {ms:.3f} ms  {4.0 * L * L * Cc * B / ms / 1e9:.1f} TFLOP/s-eq (split pass included)")
