@@ -21,6 +21,8 @@
 // Per 16x16 (query, key) tile: 15 bf16 MFMAs (240 matrix cycles) + ~210 vector cycles, against 20 fp32 MFMAs (640).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 using namespace hdiff;
@@ -31,13 +33,13 @@ namespace {
 #define X3B_ABL 0            // dev: timing ablations (bit mask), results are wrong with any bit set
 #endif
 constexpr int THREADS = 256;
-constexpr int TQ = 32;                 // queries per staged tile
+constexpr int TQ = 64;                 // queries per staged tile (two subtiles of 32 = one contraction of the q-summed products)
 constexpr int KB = 128;                // keys per workgroup block (32 per wave)
 constexpr int RROW = 48;               // bytes per query row of a piece tile (32 + 16: conflict-free ds_read_b128)
-constexpr int RPART = TQ * RROW;       // 1536
+constexpr int RPART = TQ * RROW;       // 3072
 constexpr int QA_OFF = 0, OA_OFF = 3 * RPART;
-constexpr int SL_OFF = 6 * RPART, SD_OFF = SL_OFF + TQ * 4, BUFB = SD_OFF + TQ * 4;     // 9472 bytes
-constexpr int SROW = 72;               // bytes per key row of the dS image [key][query] (64 + 8: conflict-free ds_write_b64)
+constexpr int SL_OFF = 6 * RPART, SD_OFF = SL_OFF + TQ * 4, BUFB = SD_OFF + TQ * 4;     // 18944 bytes
+constexpr int SROW = 72;               // bytes per key row of the dS image [key][32 queries] (64 + 8: conflict-free ds_write_b64)
 constexpr int SPART = 32 * SROW;       // 2304 per piece
 constexpr int SCRB = 3 * SPART;        // 6912 per wave
 constexpr int DQS = TQ + 4;            // row stride (floats) of a wave's dQ partial tile [16][DQS], aliased on its scratch
@@ -74,7 +76,10 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& h0, unsigned&
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores
 // (release fence: s_waitcnt vmcnt(0)); with one slab store per tile in flight that wait exposed the store's latency at
 // every barrier -- 23 ms of a 158 ms launch (timing ablation).  Nothing here hands global data to another wave.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void lds_barrier() {
+  if (X3B_ABL & 256) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -175,33 +180,32 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
   const int doff = 8 * (g & 1);
   const bool hi = g >> 1;
 
-  // ---- staging of one query tile: 384 chunks of 16 bytes (the row pieces of Q and dO); thread tid copies chunk tid and,
-  // in waves 0 and 1, chunk 256 + tid; -lse2 and -delta by the first 64 threads
-  unsigned goff[2];
-  int lds_off[2];
+  // ---- staging of one query tile: 768 chunks of 16 bytes (the row pieces of Q and dO), three per thread; -lse2 and
+  // -delta by the first 128 threads
+  unsigned goff[3];
+  int lds_off[3];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = (i * THREADS + tid) % 384;
-    const int sel = c / 192, cv = c - sel * 192;           // 0: Q rows, 1: dO rows
-    const int p = cv >> 6, rem = cv & 63;
+  for (int i = 0; i < 3; ++i) {
+    const int c = i * THREADS + tid;
+    const int sel = c / 384, cv = c - sel * 384;           // 0: Q rows, 1: dO rows
+    const int p = cv >> 7, rem = cv & 127;
     const int row = rem >> 1, half = rem & 1;
     goff[i] = (unsigned)(((sel == 0 ? T_QA : T_OA) * 3 + p) * piece_n * 2) + row * 32 + half * 16;
     lds_off[i] = (sel == 0 ? QA_OFF : OA_OFF) + p * RPART + row * RROW + half * 16;
   }
   const unsigned char* wsb = reinterpret_cast<const unsigned char*>(wsh);
-  const bool second = wave < 2;
-  const float* ldsrc = (tid < TQ) ? lbase + tid : dbase + (tid & (TQ - 1));     // used by the first 64 threads only
-  u32x4 stage[2];
+  const float* ldsrc = (tid < TQ) ? lbase + tid : dbase + (tid & (TQ - 1));     // used by the first 128 threads only
+  u32x4 stage[3];
   float stage_ld = 0.f;
   auto stage_load = [&](int t) {
-    stage[0] = *reinterpret_cast<const u32x4*>(wsb + goff[0] + (size_t)t * (TQ * 32));
-    if (second) stage[1] = *reinterpret_cast<const u32x4*>(wsb + goff[1] + (size_t)t * (TQ * 32));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) stage[i] = *reinterpret_cast<const u32x4*>(wsb + goff[i] + (size_t)t * (TQ * 32));
     if (tid < 2 * TQ) stage_ld = ldsrc[t * TQ];      // negated when stored: nothing here may consume a load at once
   };
   auto stage_store = [&](int buf) {
     unsigned char* tb = smem + buf * BUFB;
-    *reinterpret_cast<u32x4*>(tb + lds_off[0]) = stage[0];
-    if (second) *reinterpret_cast<u32x4*>(tb + lds_off[1]) = stage[1];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(tb + lds_off[i]) = stage[i];
     if (tid < 2 * TQ) *reinterpret_cast<float*>(tb + SL_OFF + tid * 4) = -stage_ld;    // sL then sD, contiguous
   };
 
@@ -217,8 +221,10 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
   // the dS image of this wave: [piece][key 0..31][SROW bytes of 32 queries]
   const int swaddr = i16 * SROW + 8 * g;                              // + piece * SPART + kt * 16 * SROW + jq * 32
   const int sraddr = (8 * g + (i16 >> 2)) * SROW + 8 * (i16 & 3);     // + piece * SPART + jq * 32 (+ 4 * SROW: second half)
-  // reduction of the tile's dQ over the four waves: thread = (d, two neighbouring queries) = floats 2 tid, 2 tid + 1 of the tile
-  const int rd = tid >> 4, rq = (tid & 15) * 2;
+  // reduction of the tile's dQ over the four waves: thread = floats tid, 256 + tid, 512 + tid, 768 + tid of the tile's
+  // [d][64 queries] block -- every slab instruction of a wave then covers 256 contiguous bytes (with four NEIGHBOURING
+  // floats per thread the four L2 adds of a wave hit the same eight lines back to back: 95 ms of a 225 ms launch)
+  const int rd = tid >> 6, rq = tid & 63;
 
   for (int kb = kb_begin; kb < kb_end; ++kb) {
     const int key0 = kb * KB + wave * 32;
@@ -244,144 +250,156 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
     stage_load(0);
     stage_store(0);
     __syncthreads();
+    if (!(X3B_ABL & 8)) stage_load(1);
 
-    f32x2 old = f32x2{0.f, 0.f}, old1 = f32x2{0.f, 0.f};
-    if (!(X3B_ABL & 33) && kb != kb_begin) {
-      old = *reinterpret_cast<const f32x2*>(part + tid * 2);
-      old1 = *reinterpret_cast<const f32x2*>(part + D * TQ + tid * 2);
-    }
+    // dQ goes to the key range's slab (layout [tile][d][32 queries]: 2 KB per tile, contiguous): a plain store during the
+    // range's first key block, fire-and-forget L2 float adds afterwards.  Only THIS thread ever touches its two slab words,
+    // in program order, so the sums are formed in a fixed order (bitwise reproducible) although the adder sits in L2 --
+    // and the old value never travels to the CU: no load to wait for, half the slab bytes on the CU's memory path.
+    const bool first_kb = (kb == kb_begin);
     for (int t = 0; t < ntiles; ++t) {
       const int buf = t & 1;
       const unsigned char* tb = smem + buf * BUFB;
-      if (!(X3B_ABL & 8)) stage_load(t + 1 < ntiles ? t + 1 : t);
-      // the slab values this thread stored during the previous key block (program order: no protocol needed), fetched two
-      // tiles ahead: under the slab traffic a load takes longer than one tile of work.  Slab layout [tile][d][32 queries]:
-      // 2 KB per tile, contiguous
-      float* pdst = part + (size_t)t * (D * TQ) + tid * 2;
-      f32x2 old2 = f32x2{0.f, 0.f};
-      if (!(X3B_ABL & 33) && kb != kb_begin && t + 2 < ntiles) old2 = *reinterpret_cast<const f32x2*>(pdst + 2 * D * TQ);
+      float* pdst = part + (size_t)t * (D * TQ) + tid;
 
-      u32x4 qA[2][3], oA[2][3];
+      f32x4 dQt[2][2];
 #pragma unroll
-      for (int jq = 0; jq < 2; ++jq)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          qA[jq][j] = *reinterpret_cast<const u32x4*>(tb + QA_OFF + a1addr[j] + jq * 16 * RROW);
-          oA[jq][j] = *reinterpret_cast<const u32x4*>(tb + OA_OFF + a1addr[j] + jq * 16 * RROW);
-        }
-      f32x4 negl[2], negd[2];
-#pragma unroll
-      for (int jq = 0; jq < 2; ++jq) {
-        negl[jq] = *reinterpret_cast<const f32x4*>(tb + SL_OFF + (16 * jq + 4 * g) * 4);
-        negd[jq] = *reinterpret_cast<const f32x4*>(tb + SD_OFF + (16 * jq + 4 * g) * 4);
-      }
-      u32x4 qT[3], oT[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        const unsigned char* sq = tb + QA_OFF + p * RPART + a3addr;
-        const unsigned char* so = tb + OA_OFF + p * RPART + a3addr;
-        const u32x2 q0 = lds_read_tr16(sq), q1 = lds_read_tr16(sq + 16 * RROW);
-        const u32x2 o0 = lds_read_tr16(so), o1 = lds_read_tr16(so + 16 * RROW);
-        qT[p] = u32x4{q0[0], q0[1], q1[0], q1[1]};
-        oT[p] = u32x4{o0[0], o0[1], o1[0], o1[1]};
-      }
-
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        f32x4 S[2], dP[2];
-#pragma unroll
-        for (int jq = 0; jq < 2; ++jq) {
-          f32x4 acc = negl[jq];
-#pragma unroll
-          for (int j = 0; j < 3; ++j) acc = mfma_bf16(qA[jq][j], kB[kt][j], acc);
-          S[jq] = acc;
-          acc = negd[jq];
-#pragma unroll
-          for (int j = 0; j < 3; ++j) acc = mfma_bf16(oA[jq][j], vB[kt][j], acc);
-          dP[jq] = acc;
-        }
-        u32x4 Pp[3], Sp[3];
-#pragma unroll
-        for (int jq = 0; jq < 2; ++jq) {
-          float p[4], ds[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            p[i] = __builtin_amdgcn_exp2f(S[jq][i]);
-            ds[i] = p[i] * dP[jq][i];
-          }
-          if (X3B_ABL & 16) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-              for (int pc = 0; pc < 3; ++pc) {
-                Pp[pc][2 * jq + h] = __builtin_bit_cast(unsigned, S[jq][2 * h]) + pc;
-                Sp[pc][2 * jq + h] = __builtin_bit_cast(unsigned, dP[jq][2 * h + 1]) + pc;
-              }
-          } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              unsigned h0, h1, h2;
-              split3(p[2 * h], p[2 * h + 1], h0, h1, h2);
-              Pp[0][2 * jq + h] = h0; Pp[1][2 * jq + h] = h1; Pp[2][2 * jq + h] = h2;
-              split3(ds[2 * h], ds[2 * h + 1], h0, h1, h2);
-              Sp[0][2 * jq + h] = h0; Sp[1][2 * jq + h] = h1; Sp[2][2 * jq + h] = h2;
-            }
-          }
-          // the packed dS pieces of (key i16 of tile kt, queries 16 jq + 4g ..+3) into the wave's [key][query] image
-          if (!(X3B_ABL & 4)) {
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
-              *reinterpret_cast<u32x2*>(scr + pc * SPART + kt * 16 * SROW + jq * 32 + swaddr) = u32x2{Sp[pc][2 * jq], Sp[pc][2 * jq + 1]};
-          }
-        }
-#pragma unroll
-        for (int term = 5; term >= 0; --term) {      // small terms first
-          dVt[kt] = mfma_bf16(oT[TERM_A[term]], Pp[TERM_B[term]], dVt[kt]);
-          dKt[kt] = mfma_bf16(qT[TERM_A[term]], Sp[TERM_B[term]], dKt[kt]);
-        }
-      }
-
-      // ---- dQ^T of the tile over this wave's 32 keys: the dS image read back transposed, keys along the contraction
-      asm volatile("" ::: "memory");
-      f32x4 dQt[2];
-#pragma unroll
-      for (int jq = 0; jq < 2; ++jq) {
-        u32x4 sT[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const unsigned char* src = scr + p * SPART + jq * 32 + sraddr;
-          const u32x2 lo = lds_read_tr16(src), hi2 = lds_read_tr16(src + 4 * SROW);
-          sT[p] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
-        }
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int term = 5; term >= 0; --term) acc = mfma_bf16(kT[TERM_A[term]], sT[TERM_B[term]], acc);
-        dQt[jq] = acc;
-      }
-      asm volatile("" ::: "memory");
-      // the wave's partial tile [d][query] over its own scratch (its reads above are done: same wave, in order)
-      if (X3B_ABL & 2) {
-        if (dQt[0][0] + dQt[1][0] + dQt[0][1] + dQt[1][1] + dQt[0][2] + dQt[1][2] + dQt[0][3] + dQt[1][3] == 12345.f) *pdst = 1.f;
-      } else {
+      for (int sub = 0; sub < 2; ++sub) {
+        const unsigned char* sb = tb + sub * 32 * RROW;
+        u32x4 qA[2][3], oA[2][3];
 #pragma unroll
         for (int jq = 0; jq < 2; ++jq)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sdq[(4 * g + r) * DQS + 16 * jq + i16] = dQt[jq][r];
+          for (int j = 0; j < 3; ++j) {
+            qA[jq][j] = *reinterpret_cast<const u32x4*>(sb + QA_OFF + a1addr[j] + jq * 16 * RROW);
+            oA[jq][j] = *reinterpret_cast<const u32x4*>(sb + OA_OFF + a1addr[j] + jq * 16 * RROW);
+          }
+        f32x4 negl[2], negd[2];
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) {
+          negl[jq] = *reinterpret_cast<const f32x4*>(tb + SL_OFF + (32 * sub + 16 * jq + 4 * g) * 4);
+          negd[jq] = *reinterpret_cast<const f32x4*>(tb + SD_OFF + (32 * sub + 16 * jq + 4 * g) * 4);
+        }
+        u32x4 qT[3], oT[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const unsigned char* sq = sb + QA_OFF + p * RPART + a3addr;
+          const unsigned char* so = sb + OA_OFF + p * RPART + a3addr;
+          const u32x2 q0 = lds_read_tr16(sq), q1 = lds_read_tr16(sq + 16 * RROW);
+          const u32x2 o0 = lds_read_tr16(so), o1 = lds_read_tr16(so + 16 * RROW);
+          qT[p] = u32x4{q0[0], q0[1], q1[0], q1[1]};
+          oT[p] = u32x4{o0[0], o0[1], o1[0], o1[1]};
+        }
+
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          f32x4 S[2], dP[2];
+#pragma unroll
+          for (int jq = 0; jq < 2; ++jq) {
+            f32x4 acc = negl[jq];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc = mfma_bf16(qA[jq][j], kB[kt][j], acc);
+            S[jq] = acc;
+            acc = negd[jq];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc = mfma_bf16(oA[jq][j], vB[kt][j], acc);
+            dP[jq] = acc;
+          }
+          u32x4 Pp[3], Sp[3];
+#pragma unroll
+          for (int jq = 0; jq < 2; ++jq) {
+            float p[4], ds[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              p[i] = __builtin_amdgcn_exp2f(S[jq][i]);
+              ds[i] = p[i] * dP[jq][i];
+            }
+            if (X3B_ABL & 16) {
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                  Pp[pc][2 * jq + h] = __builtin_bit_cast(unsigned, S[jq][2 * h]) + pc;
+                  Sp[pc][2 * jq + h] = __builtin_bit_cast(unsigned, dP[jq][2 * h + 1]) + pc;
+                }
+            } else {
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                unsigned h0, h1, h2;
+                split3(p[2 * h], p[2 * h + 1], h0, h1, h2);
+                Pp[0][2 * jq + h] = h0; Pp[1][2 * jq + h] = h1; Pp[2][2 * jq + h] = h2;
+                split3(ds[2 * h], ds[2 * h + 1], h0, h1, h2);
+                Sp[0][2 * jq + h] = h0; Sp[1][2 * jq + h] = h1; Sp[2][2 * jq + h] = h2;
+              }
+            }
+            // the packed dS pieces of (key i16 of tile kt, queries 16 jq + 4g ..+3) into the wave's [key][query] image
+            if (!(X3B_ABL & 4)) {
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc)
+                *reinterpret_cast<u32x2*>(scr + pc * SPART + kt * 16 * SROW + jq * 32 + swaddr) = u32x2{Sp[pc][2 * jq], Sp[pc][2 * jq + 1]};
+            }
+          }
+#pragma unroll
+          for (int term = 5; term >= 0; --term) {      // small terms first
+            dVt[kt] = mfma_bf16(oT[TERM_A[term]], Pp[TERM_B[term]], dVt[kt]);
+            dKt[kt] = mfma_bf16(qT[TERM_A[term]], Sp[TERM_B[term]], dKt[kt]);
+          }
+        }
+
+        // ---- dQ^T of the subtile over this wave's 32 keys: the dS image read back transposed, keys along the contraction
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) {
+          u32x4 sT[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const unsigned char* src = scr + p * SPART + jq * 32 + sraddr;
+            const u32x2 lo = lds_read_tr16(src), hi2 = lds_read_tr16(src + 4 * SROW);
+            sT[p] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
+          }
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int term = 5; term >= 0; --term) acc = mfma_bf16(kT[TERM_A[term]], sT[TERM_B[term]], acc);
+          dQt[sub][jq] = acc;
+        }
+        asm volatile("" ::: "memory");      // the next subtile's image stores stay behind these reads (same wave: in order)
+      }
+
+      // the wave's partial tile [d][query] over its own scratch (its reads above are done: same wave, in order)
+      if (X3B_ABL & 2) {
+        if (dQt[0][0][0] + dQt[0][1][0] + dQt[1][0][1] + dQt[1][1][1] == 12345.f) *pdst = 1.f;
+        stage_store(buf ^ 1);
+        if (!(X3B_ABL & 8)) stage_load(t + 2 < ntiles ? t + 2 : t);
+      } else {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int jq = 0; jq < 2; ++jq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sdq[(4 * g + r) * DQS + 32 * sub + 16 * jq + i16] = dQt[sub][jq][r];
         lds_barrier();
         const float* s0 = reinterpret_cast<const float*>(smem + 2 * BUFB) + rd * DQS + rq;
-        f32x2 sum = *reinterpret_cast<const f32x2*>(s0);
+        f32x4 sum;
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-          const f32x2 v = *reinterpret_cast<const f32x2*>(s0 + w * (SCRB / 4));
-          sum[0] += v[0]; sum[1] += v[1];
+        for (int r = 0; r < 4; ++r) {
+          float v = s0[4 * r * DQS];
+#pragma unroll
+          for (int w = 1; w < 4; ++w) v += s0[4 * r * DQS + w * (SCRB / 4)];
+          sum[r] = v * a.inv_sqrt_d;
         }
-        old[0] += sum[0] * a.inv_sqrt_d;
-        old[1] += sum[1] * a.inv_sqrt_d;
-        if (!(X3B_ABL & 65) || t == 0) *reinterpret_cast<f32x2*>(pdst) = old;
-        old = old1;
-        old1 = old2;
+        // tile t + 1 into LDS, then the loads of tile t + 2
+        stage_store(buf ^ 1);
+        if (!(X3B_ABL & 8)) stage_load(t + 2 < ntiles ? t + 2 : t);
+        if (!(X3B_ABL & 65) || t == 0) {
+          if (first_kb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pdst[256 * r] = sum[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) unsafeAtomicAdd(pdst + 256 * r, sum[r]);
+          }
+        }
       }
-      stage_store(buf ^ 1);
       lds_barrier();
     }
 
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
 }
 
 // dqkv[b][head * 16 + d][q] (Q third) = 1/sqrt(d) * sum over key ranges, in order, of the tile-major slabs
-// [split][B][heads][L / 32][16][32].  Thread = four neighbouring queries of one (d, tile).
+// [split][B][heads][L / 64][16][64].  Thread = four neighbouring queries of one (d, tile).
 __global__ void mha_dq_reduce_x3_kernel(const float* __restrict__ part, float* __restrict__ dqkv, int nsplit, int C, int L,
                                         size_t split_stride) {
   const int b = blockIdx.y;
@@ -409,11 +427,11 @@ __global__ void mha_dq_reduce_x3_kernel(const float* __restrict__ part, float* _
   float* dst = dqkv + (size_t)b * 3 * per_sample;
   const size_t n4 = per_sample >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    // i indexes the slab in its own order: head, tile, d, 8 groups of 4 queries
+    // i indexes the slab in its own order: head, tile, d, 16 groups of 4 queries
     f32x4 acc = reinterpret_cast<const f32x4*>(src)[i];
     for (int sp = 1; sp < nsplit; ++sp) acc += reinterpret_cast<const f32x4*>(src + (size_t)sp * split_stride)[i];
-    const int q4 = (int)(i & 7), d = (int)((i >> 3) & 15);
-    const size_t ht = i >> 7;                      // head * (L / 32) + tile
+    const int q4 = (int)(i & 15), d = (int)((i >> 4) & 15);
+    const size_t ht = i >> 8;                      // head * (L / 64) + tile
     const int tiles = L / TQ;
     const size_t head = ht / tiles, tile = ht - head * tiles;
     reinterpret_cast<f32x4*>(dst + (head * 16 + d) * (size_t)L + tile * TQ)[q4] = acc;

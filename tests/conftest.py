@@ -16,7 +16,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # default is bf16x3 (HDIFF_CONTRACT=f32 for the other); every fixture restores the mode it found.
 CONTRACT_MODULES = {"test_gpu_model", "test_gpu_configs", "test_gpu_end_to_end", "test_gpu_tree_b", "test_gpu_ops",
                     "test_gpu_fullsize", "test_gpu_backward"}
-CONTRACT_INDEPENDENT = {"test_c3_attention_backward_full_length", "test_small_ops_match_torch",
+CONTRACT_INDEPENDENT = {"test_small_ops_match_torch",
                         "test_linear_rows_and_gather", "test_linear_and_embedding_backward", "test_downsample_and_tconv_backward",
                         "test_ddpm_step_bit_exact_and_nan_flag", "test_ddpm_step_loop_bookkeeping", "test_q_sample_bit_exact_and_clip",
                         "test_randn_moments_and_determinism", "test_groupnorm_scale_shift", "test_groupnorm_fused_finalize_equals_two_launches",

@@ -151,6 +151,63 @@ def test_flash_attention_backward(d, H, W, B):
     close(h.grad, r.grad.float(), rel=1e-4, abs_=2e-6, what=f"flash bwd d={d} L={H * W}")
 
 
+def test_split_bf16_attention_backward_is_another_program_fp32_class_and_reproducible():
+    """attention_bwd_x3.hip (d_head 16, bf16x3 mode): B = 4, L = 8192 gives each workgroup TWO key blocks, so the dQ slab
+    takes the plain store of the first block AND the in-order L2 float adds of the second.  The result must differ from the
+    fp32-input kernel's (another program ran), sit in the same error class against float64, and repeat bit for bit."""
+    import ctypes as C
+    from hdiff_amd import _capi
+    lib = _capi.lib()
+    heads, d, L, B = 8, 16, 8192, 4
+    Cc = heads * d
+    g = torch.Generator().manual_seed(11)
+    qkv = (torch.randn(B, 3 * Cc, L, generator=g) * 1.3).to(DEV)
+    d_o = torch.randn(B, Cc, L, generator=g).to(DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    before = lib.hdiff_get_contraction_mode()
+
+    def bwd(mode):
+        _capi.check(lib.hdiff_set_contraction_mode(mode))
+        o = torch.empty(B, Cc, L, device=DEV)
+        lse = torch.empty(B, heads, L, device=DEV)
+        _capi.check(lib.hdiff_mha_flash_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, Cc, heads, L, s), "fwd")
+        delta = torch.empty(B, heads, L, device=DEV)
+        dqkv = torch.full_like(qkv, float("nan"))
+        need = C.c_int64(0)
+        _capi.check(lib.hdiff_mha_flash_bwd_workspace(B, Cc, heads, L, C.byref(need)), "ws")
+        ws = torch.full((max(need.value, 1),), float("nan"), device=DEV)
+        _capi.check(lib.hdiff_mha_flash_bwd(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                            dqkv.data_ptr(), ws.data_ptr(), B, Cc, heads, L, s), "bwd")
+        torch.cuda.synchronize()
+        return dqkv, need.value
+
+    try:
+        g32, need32 = bwd(0)
+        gx3, needx3 = bwd(1)
+        gx3_again, _ = bwd(1)
+    finally:
+        _capi.check(lib.hdiff_set_contraction_mode(before))
+    assert needx3 > need32, "the split-bf16 backward asks for its piece tensors on top of the slabs"
+    assert torch.isfinite(gx3).all()
+    assert not torch.equal(gx3, g32), "the split-bf16 backward did not run"
+    assert torch.equal(gx3, gx3_again), "not bitwise reproducible"
+    # float64 reference of two (sample, head) pairs, every position
+    for (b, h) in ((0, 0), (3, 5)):
+        sl = slice(h * d, (h + 1) * d)
+        Q = qkv[b, sl].double().t(); K = qkv[b, Cc + h * d:Cc + (h + 1) * d].double().t()
+        V = qkv[b, 2 * Cc + h * d:2 * Cc + (h + 1) * d].double().t(); dO = d_o[b, sl].double().t()
+        P = torch.softmax(Q @ K.t() / math.sqrt(d), dim=-1)
+        dP = dO @ V.t()
+        dS = P * (dP - (dO * (P @ V)).sum(-1, keepdim=True))
+        ref = {"dQ": (dS @ K / math.sqrt(d)).t(), "dK": (dS.t() @ Q / math.sqrt(d)).t(), "dV": (P.t() @ dO).t()}
+        for i, name in enumerate(("dQ", "dK", "dV")):
+            rows = slice(i * Cc + h * d, i * Cc + (h + 1) * d)
+            mag = ref[name].abs().max().item()
+            ex3 = (gx3[b, rows].double() - ref[name]).abs().max().item()
+            e32 = (g32[b, rows].double() - ref[name]).abs().max().item()
+            assert ex3 <= 3e-5 * mag and ex3 <= 4.0 * e32 + 1e-7 * mag, (name, b, h, ex3, e32, mag)
+
+
 def test_linear_and_embedding_backward():
     g = torch.Generator().manual_seed(2)
     table = torch.randn(12, 64, generator=g)
