@@ -35,10 +35,13 @@ namespace {
 constexpr int THREADS = 256;
 constexpr int TQ = 64;                 // queries per staged tile (two subtiles of 32 = one contraction of the q-summed products)
 constexpr int KB = 128;                // keys per workgroup block (32 per wave)
-constexpr int RROW = 48;               // bytes per query row of a piece tile (32 + 16: conflict-free ds_read_b128)
-constexpr int RPART = TQ * RROW;       // 3072
+constexpr int RROW = 32;               // bytes per query row of a piece tile: NO padding -- with ds_read_b128's real lane groups
+                                       // ({0-3, 12-15, 20-27}, ...) the plain 32-byte rows are conflict-free for the row reads,
+                                       // the transposed reads and the staging stores alike (48-byte rows: a third of all LDS
+                                       // cycles were bank conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.35)
+constexpr int RPART = TQ * RROW;       // 2048
 constexpr int QA_OFF = 0, OA_OFF = 3 * RPART;
-constexpr int SL_OFF = 6 * RPART, SD_OFF = SL_OFF + TQ * 4, BUFB = SD_OFF + TQ * 4;     // 18944 bytes
+constexpr int SL_OFF = 6 * RPART, SD_OFF = SL_OFF + TQ * 4, BUFB = SD_OFF + TQ * 4;     // 12800 bytes
 constexpr int SROW = 72;               // bytes per key row of the dS image [key][32 queries] (64 + 8: conflict-free ds_write_b64)
 constexpr int SPART = 32 * SROW;       // 2304 per piece
 constexpr int SCRB = 3 * SPART;        // 6912 per wave
