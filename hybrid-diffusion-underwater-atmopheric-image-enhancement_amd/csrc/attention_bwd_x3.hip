@@ -19,6 +19,9 @@
 //                                                    instruction -- no third split, no 2-byte stores
 //   dQ of a tile is summed over the four waves in a fixed order and added to the key range's slab (attention_bwd.hip).
 // Per 16x16 (query, key) tile: 15 bf16 MFMAs (240 matrix cycles) + ~210 vector cycles, against 20 fp32 MFMAs (640).
+// (Tried and removed: the tile as a software pipeline over its four (subtile, key tile) units, the scores of unit u + 1
+// issued ahead of unit u's exp / split stream -- 141.8 against 139.4 ms on the same box; as in the forward kernels the two
+// waves of a SIMD already overlap each other's matrix and vector phases, and the longer in-order stream only adds waits.)
 #include <stdlib.h>
 
 #include <type_traits>
