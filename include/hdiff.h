@@ -200,8 +200,12 @@ int hdiff_mha_wide_fwd(const float* qkv, float* o, int B, int C, int L, hdiff_st
 /* Backward of the core (autograd of nn.MultiheadAttention, TrainCondition.py:60): dqkv [B][3C][L] from dO [B][C][L].
  * lse2 is the forward's log2-domain log-sum-exp; delta is a [B][heads][L] workspace (rowsum(dO o O), written here).
  * P is recomputed, never stored; five MFMA products per tile in ONE kernel: a workgroup owns a key range (dK, dV in
- * registers) and adds its dQ tiles to the partial slab of that range in ws, summed in range order afterwards -- no atomics,
- * bitwise reproducible.  hdiff_mha_flash_bwd_workspace gives the size of ws in floats (0: ws may be NULL). */
+ * registers) and adds its dQ tiles to the partial slab of that range in ws, summed in range order afterwards -- every slab
+ * word is only ever touched by one thread, in program order: bitwise reproducible.  In the bf16x3 contraction mode at
+ * d_head 16 (L a multiple of 256, >= 512) the five products run on the bf16 matrix core (attention_bwd_x3.hip); ws then
+ * also holds the five bf16 piece tensors of Q, K, K^T, V, dO (30 bytes per element of a [B][C][L] tensor) and the slab
+ * words after a range's first key block are accumulated by in-order L2 float adds.  hdiff_mha_flash_bwd_workspace gives
+ * the size of ws in floats for the CURRENT contraction mode (0: ws may be NULL). */
 int hdiff_mha_flash_bwd_workspace(int B, int C, int heads, int L, int64_t* n_floats);
 int hdiff_mha_flash_bwd(const float* qkv, const float* o, const float* d_o, const float* lse2, float* delta, float* dqkv,
                         float* ws, int B, int C, int heads, int L, hdiff_stream_t stream);

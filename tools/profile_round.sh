@@ -27,6 +27,8 @@ run_pmc x3_sq1 $SQ1 -- python3 tools/attn_once.py 16
 run_pmc x3_sq2 $SQ2 -- python3 tools/attn_once.py 16
 HDIFF_CONTRACT=f32 run_pmc attn_sq1 $SQ1 -- python3 tools/attn_once.py 16
 run_pmc bwd_sq1 $SQ1 -- python3 tools/attn_bwd_once.py 4
+run_pmc bwd_sq2 $SQ2 -- python3 tools/attn_bwd_once.py 4
+HDIFF_CONTRACT=f32 run_pmc bwdf32_sq1 $SQ1 -- python3 tools/attn_bwd_once.py 4
 run_pmc convx3_sq1 $SQ1 -- python3 tools/conv_once.py 16 128 128 256 3 gn
 HDIFF_CONTRACT=f32 run_pmc conv_sq1 $SQ1 -- python3 tools/conv_once.py 16 128 128 256 3 gn
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -35,14 +37,16 @@ for c in FETCH_SIZE WRITE_SIZE; do
   HDIFF_CONTRACT=f32 run_pmc conv_$c $c -- python3 tools/conv_once.py 16 128 128 256 3 gn
   run_pmc gn_$c $c -- python3 tools/gn_stats_once.py 16 128 256
   run_pmc bwd_$c $c -- python3 tools/attn_bwd_once.py 4
+  HDIFF_CONTRACT=f32 run_pmc bwdf32_$c $c -- python3 tools/attn_bwd_once.py 4
 done
 {
   for d in x3_sq1 x3_sq2; do echo "## $d: rocprofv3 --pmc ... -- python3 tools/attn_once.py 16   (bf16x3: split pass + mha_flash_fwd_x3_kernel<16, 4, true>; rocprofv3 prints that name mangled: its demangler does not know __bf16)"; python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv "mha_flash_fwd_x3_kernelILi16"; done
   echo "## attn_sq1: HDIFF_CONTRACT=f32 ... -- python3 tools/attn_once.py 16"; python3 tools/pmc_summary.py $P/attn_sq1/pmc_counter_collection.csv "fast_kernel<16"
-  echo "## bwd_sq1: ... -- python3 tools/attn_bwd_once.py 4"; python3 tools/pmc_summary.py $P/bwd_sq1/pmc_counter_collection.csv mha_bwd_fused
+  for d in bwd_sq1 bwd_sq2; do echo "## $d: ... -- python3 tools/attn_bwd_once.py 4   (bf16x3: split pass + mha_bwd_x3_kernel + slab reduce)"; python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv mha_bwd_x3_kernel; done
+  echo "## bwdf32_sq1: HDIFF_CONTRACT=f32 ... -- python3 tools/attn_bwd_once.py 4"; python3 tools/pmc_summary.py $P/bwdf32_sq1/pmc_counter_collection.csv mha_bwd_fused
   echo "## convx3_sq1: ... -- python3 tools/conv_once.py 16 128 128 256 3 gn   (bf16x3)"; python3 tools/pmc_summary.py $P/convx3_sq1/pmc_counter_collection.csv conv3x3_x3
   echo "## conv_sq1: HDIFF_CONTRACT=f32 ... -- python3 tools/conv_once.py 16 128 128 256 3 gn"; python3 tools/pmc_summary.py $P/conv_sq1/pmc_counter_collection.csv conv_igemm
-  for k in x3 attn conv gn bwd; do for c in FETCH_SIZE WRITE_SIZE; do echo "## ${k}_$c (KiB per dispatch)"; python3 tools/pmc_summary.py $P/${k}_$c/pmc_counter_collection.csv | grep -A1 -E "mha_flash_fwd_x3_kernelILi16|qkv_split3|fast_kernel<16|igemm_kernel<2, 8, 12, 5, 1|gn_stats_kernel|bwd_fused|dq_reduce|delta"; done; done
+  for k in x3 attn conv gn bwd bwdf32; do for c in FETCH_SIZE WRITE_SIZE; do echo "## ${k}_$c (KiB per dispatch)"; python3 tools/pmc_summary.py $P/${k}_$c/pmc_counter_collection.csv | grep -A1 -E "mha_flash_fwd_x3_kernelILi16|qkv_split3|fast_kernel<16|igemm_kernel<2, 8, 12, 5, 1|gn_stats_kernel|bwd_fused|bwd_x3|bwd_split3|dq_reduce|delta"; done; done
 } > $P/pmc_summary.txt
 python3 tools/traffic_json.py $P $COMMIT --out $P/roofline_traffic.json > $P/traffic_line.json 2> $P/traffic.err
 ls $P
