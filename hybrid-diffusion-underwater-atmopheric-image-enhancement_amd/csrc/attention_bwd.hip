@@ -518,7 +518,7 @@ template <int D>
 int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* lse2, float* delta, float* dqkv, float* ws,
                int B, int C, int heads, int L, hipStream_t stream) {
   if constexpr (D == 16) {
-    if (mha_bwd_x3_applicable(C, heads, L)) {       // bf16x3 mode: all five products on the bf16 matrix core
+    if (mha_bwd_x3_applicable(B, C, heads, L)) {       // bf16x3 mode: all five products on the bf16 matrix core
       HDIFF_CHECK_ARG(ws != nullptr, "mha_flash_bwd: this shape needs a workspace (hdiff_mha_flash_bwd_workspace)");
       const int total = B * heads * L;
       (void)hipGetLastError();
@@ -567,7 +567,7 @@ extern "C" int hdiff_mha_flash_bwd_workspace(int B, int C, int heads, int L, int
   HDIFF_CHECK_ARG(n_floats, "mha_flash_bwd_workspace: null pointer");
   HDIFF_CHECK_ARG(B > 0 && L > 0 && heads > 0 && C % heads == 0, "mha_flash_bwd_workspace: bad sizes B=%d C=%d heads=%d L=%d",
                   B, C, heads, L);
-  if (C / heads == 16 && mha_bwd_x3_applicable(C, heads, L)) {
+  if (C / heads == 16 && mha_bwd_x3_applicable(B, C, heads, L)) {
     *n_floats = mha_bwd_x3_workspace_floats(B, C, heads, L);
     return HDIFF_OK;
   }
