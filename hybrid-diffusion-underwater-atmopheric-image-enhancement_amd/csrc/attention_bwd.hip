@@ -567,12 +567,14 @@ extern "C" int hdiff_mha_flash_bwd_workspace(int B, int C, int heads, int L, int
   HDIFF_CHECK_ARG(n_floats, "mha_flash_bwd_workspace: null pointer");
   HDIFF_CHECK_ARG(B > 0 && L > 0 && heads > 0 && C % heads == 0, "mha_flash_bwd_workspace: bad sizes B=%d C=%d heads=%d L=%d",
                   B, C, heads, L);
-  if (C / heads == 16 && mha_bwd_x3_applicable(B, C, heads, L)) {
-    *n_floats = mha_bwd_x3_workspace_floats(B, C, heads, L);
-    return HDIFF_OK;
-  }
   const BwdGeom g = bwd_geometry(B, heads, L, C / heads);
   *n_floats = (g.nsplit > 1) ? (int64_t)g.nsplit * B * C * L : 0;
+  // The answer does not depend on the contraction mode: a caller that sizes the buffer, switches the mode and then calls
+  // must not overrun it (the call takes no size).  Shapes the split-bf16 kernel covers get the larger of the two needs.
+  if (C / heads == 16 && mha_bwd_x3_shape_ok(B, C, heads, L)) {
+    const int64_t x3 = mha_bwd_x3_workspace_floats(B, C, heads, L);
+    if (x3 > *n_floats) *n_floats = x3;
+  }
   return HDIFF_OK;
 }
 

@@ -460,13 +460,15 @@ X3Geom x3_geometry(int B, int heads, int L) {
 
 namespace hdiff {
 
+// shapes the kernel covers: at least one 128-key block per CU -- below that (one sample at L <= 1024) the split pass and the
+// slab reduce cost more than the matrix core gains (56 vs 47 us at B = 1, L = 1024; 0.62 vs 0.94 ms at B = 4, L = 4096)
+bool mha_bwd_x3_shape_ok(int B, int C, int heads, int L) {
+  return C / heads == 16 && L % 256 == 0 && L >= 512 && (int64_t)B * heads * (L / KB) >= 256;
+}
 bool mha_bwd_x3_applicable(int B, int C, int heads, int L) {
   static const char* e = getenv("HDIFF_BWD_X3");          // dev knob: 0 = keep the fp32-input kernel in every mode
   if (e && atoi(e) == 0) return false;
-  // at least one 128-key block per CU: below that (one sample at L <= 1024) the split pass and the slab reduce cost more than
-  // the matrix core gains (56 vs 47 us at B = 1, L = 1024; 0.62 vs 0.94 ms at B = 4, L = 4096)
-  return contraction_mode() == HDIFF_CONTRACT_BF16X3 && C / heads == 16 && L % 256 == 0 && L >= 512 &&
-         (int64_t)B * heads * (L / KB) >= 256;
+  return contraction_mode() == HDIFF_CONTRACT_BF16X3 && mha_bwd_x3_shape_ok(B, C, heads, L);
 }
 
 // slabs (tile-major, one per key range: even a single range goes through the reduce kernel, which restores the [C][L]

@@ -99,7 +99,8 @@ void launch_conv3x3_x3(const ConvX3K& k, int B, hipStream_t stream);
 int contraction_mode();   // HDIFF_CONTRACT_*
 
 // attention_bwd_x3.hip: the attention backward at d_head 16 in the split-bf16 formulation (dispatched from attention_bwd.hip)
-bool mha_bwd_x3_applicable(int B, int C, int heads, int L);
+bool mha_bwd_x3_shape_ok(int B, int C, int heads, int L);     // the shape alone (mode-independent)
+bool mha_bwd_x3_applicable(int B, int C, int heads, int L);   // shape AND the bf16x3 contraction mode
 int64_t mha_bwd_x3_workspace_floats(int B, int C, int heads, int L);   // dQ slabs + piece tensors
 void launch_mha_bwd_x3(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, float* ws, int B,
                        int C, int heads, int L, hipStream_t stream);

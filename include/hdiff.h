@@ -205,7 +205,7 @@ int hdiff_mha_wide_fwd(const float* qkv, float* o, int B, int C, int L, hdiff_st
  * d_head 16 (L a multiple of 256, >= 512) the five products run on the bf16 matrix core (attention_bwd_x3.hip); ws then
  * also holds the five bf16 piece tensors of Q, K, K^T, V, dO (30 bytes per element of a [B][C][L] tensor) and the slab
  * words after a range's first key block are accumulated by in-order L2 float adds.  hdiff_mha_flash_bwd_workspace gives
- * the size of ws in floats for the CURRENT contraction mode (0: ws may be NULL). */
+ * the size of ws in floats: a function of the shape only, large enough for either contraction mode (0: ws may be NULL). */
 int hdiff_mha_flash_bwd_workspace(int B, int C, int heads, int L, int64_t* n_floats);
 int hdiff_mha_flash_bwd(const float* qkv, const float* o, const float* d_o, const float* lse2, float* delta, float* dqkv,
                         float* ws, int B, int C, int heads, int L, hdiff_stream_t stream);

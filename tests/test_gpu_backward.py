@@ -187,7 +187,7 @@ def test_split_bf16_attention_backward_is_another_program_fp32_class_and_reprodu
         gx3_again, _ = bwd(1)
     finally:
         _capi.check(lib.hdiff_set_contraction_mode(before))
-    assert needx3 > need32, "the split-bf16 backward asks for its piece tensors on top of the slabs"
+    assert needx3 == need32, "the workspace size must not depend on the contraction mode (the call takes no size)"
     assert torch.isfinite(gx3).all()
     assert not torch.equal(gx3, g32), "the split-bf16 backward did not run"
     assert torch.equal(gx3, gx3_again), "not bitwise reproducible"
