@@ -7,7 +7,7 @@
 //   mha_bwd_split3_kernel   Q (pre-scaled by log2(e)/sqrt(d)), K, V, dO -> bf16 pieces, once per tensor, as rows [L][16]
 //                           (plus K^T [16][L], read once per key block): 5 piece tensors, 480 bytes per position and head.
 //   mha_bwd_x3_kernel       a workgroup owns key blocks of 128 keys (32 per wave: K, V, K^T pieces in registers as MFMA
-//                           operands) and sweeps all queries in tiles of 32 staged through LDS:
+//                           operands) and sweeps all queries in tiles of 64 (two subtiles of 32) staged through LDS:
 //       S  = Q K^T - lse2 ,  dP = dO V^T - delta     rows = queries (registers), columns = keys (lanes); 3 MFMAs each per
 //                                                    16x16 tile (two piece products along the 32-wide contraction)
 //       P = exp2(S) ; dS = P o dP ; both split in registers (v_and / v_sub / v_perm only)
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
     __syncthreads();
     if (!(X3B_ABL & 8)) stage_load(1);
 
-    // dQ goes to the key range's slab (layout [tile][d][32 queries]: 2 KB per tile, contiguous): a plain store during the
-    // range's first key block, fire-and-forget L2 float adds afterwards.  Only THIS thread ever touches its two slab words,
+    // dQ goes to the key range's slab (layout [tile][d][64 queries]: 4 KB per tile, contiguous): a plain store during the
+    // range's first key block, fire-and-forget L2 float adds afterwards.  Only THIS thread ever touches its four slab words,
     // in program order, so the sums are formed in a fixed order (bitwise reproducible) although the adder sits in L2 --
     // and the old value never travels to the CU: no load to wait for, half the slab bytes on the CU's memory path.
     const bool first_kb = (kb == kb_begin);
