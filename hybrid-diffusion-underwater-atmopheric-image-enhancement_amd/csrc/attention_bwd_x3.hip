@@ -135,7 +135,8 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_split3_kernel(const float* __
   }
   if (t_tr >= 0) {
     __bf16* dst = base + (size_t)t_tr * 3 * piece;
-    for (int l2 = blockIdx.x * THREADS / 2 + threadIdx.x; l2 < (blockIdx.x + 1) * THREADS / 2 && 2 * l2 < L; l2 += THREADS) {
+    const int l2 = (int)blockIdx.x * (THREADS / 2) + (int)threadIdx.x;       // the block's 256 positions = 128 pairs: half the threads
+    if ((int)threadIdx.x < THREADS / 2 && 2 * l2 < L) {
 #pragma unroll 4
       for (int d = 0; d < D; ++d) {
         const f32x2 v = *reinterpret_cast<const f32x2*>(src + (size_t)d * L + 2 * l2);
