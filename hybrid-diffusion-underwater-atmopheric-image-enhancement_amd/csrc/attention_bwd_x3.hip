@@ -450,6 +450,16 @@ X3Geom x3_geometry(int B, int heads, int L) {
   X3Geom g;
   g.nkb_total = L / KB;
   int want = cdiv(1024, B * heads);                      // ~2 rounds of 2 workgroups per CU on 256 CUs
+  // At larger batches that leaves few key ranges per (sample, head) pair, and the workgroups of a pair are the ones that share
+  // its Q / dO tile stream in their XCD's L2: up to 16 ranges per pair (batch 16: 567 -> 553 ms per launch; 32: 547) as
+  // long as the slabs stay below 16 GiB.
+  {
+    const long long per_range = (long long)B * heads * 16 * L * 4;
+    int cap = (int)((16ll << 30) / per_range);
+    int more = 16 < cap ? 16 : cap;
+    if (more > want) want = more;
+  }
+  { static const char* e = getenv("HDIFF_BWD_X3_WANT"); const int v = e ? atoi(e) : 0; if (v > want) want = v; }   // dev knob
   if (want > g.nkb_total) want = g.nkb_total;
   if (want < 1) want = 1;
   g.per = cdiv(g.nkb_total, want);
