@@ -139,8 +139,9 @@ class UpSample(nn.Module, _EagerMixin):
 class AttnBlock(nn.Module, _EagerMixin):
     """GroupNorm -> 1x1 q, k, v -> softmax(q k^T * C^-1/2) v (ONE head of width in_ch) -> 1x1 proj -> x + h
     (reference ModelCondition.py:92-120).  The reference's UNet never instantiates it (ResBlock uses
-    nn.MultiheadAttention instead, :189); it is provided because the module is part of the file's surface.  Inference only:
-    heads up to 64 channels wide run on the flash kernel, wider ones on a plain row-per-workgroup kernel."""
+    nn.MultiheadAttention instead, :189); it is provided because the module is part of the file's surface.  Heads up to 64
+    channels wide run on the flash kernel, wider ones on a plain row-per-workgroup kernel; with gradients enabled the block
+    goes through autograd.attn_block (hand-written backward: hdiff_mha_wide_bwd, hdiff_gn_affine_bwd, the conv backwards)."""
 
     def __init__(self, in_ch):
         super().__init__()
@@ -153,8 +154,8 @@ class AttnBlock(nn.Module, _EagerMixin):
     def forward(self, x):
         x = _inputs(x=x)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("hdiff: AttnBlock (unused by the reference's UNet) runs inference only on the HIP path; "
-                                      "call it under torch.no_grad()")
+            from ..autograd import attn_block
+            return attn_block(self, x)
         B, Cc, H, W = (int(v) for v in x.shape)
         with torch.cuda.device(x.device):
             plan = E.Plan(x.device)

@@ -433,12 +433,85 @@ class _AddFn(Function):
         return d, d
 
 
+class _GNAffineFn(Function):
+    """nn.GroupNorm(32, C) with no activation behind it -- AttnBlock's pre-norm (ModelCondition.py:103)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        x = x.contiguous()
+        lib = _capi.lib()
+        B, Cc, H, W = (int(v) for v in x.shape)
+        scale, shift, mean, rstd = _gn_stats(x, None, gamma, beta, B, H * W)
+        y = torch.empty_like(x)
+        _capi.check(lib.hdiff_gn_affine_apply(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, Cc, H * W,
+                                              _stream(x.device)), "gn_affine_apply")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        lib = _capi.lib()
+        B, Cc, H, W = (int(v) for v in x.shape)
+        dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(beta)
+        ws = torch.empty(2 * B * Cc + 2 * B * GN_GROUPS, device=x.device)
+        _capi.check(lib.hdiff_gn_affine_bwd(x.data_ptr(), Cc, B, H * W, GN_GROUPS, dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), dx.data_ptr(), dg.data_ptr(),
+                                            db.data_ptr(), _stream(x.device)), "gn_affine_bwd")
+        return dx, dg, db
+
+
+class _SingleHeadFn(Function):
+    """softmax(q k^T * C^-1/2) v with ONE head of width C on stacked [q | k | v] rows -- the core of AttnBlock
+    (ModelCondition.py:109-116).  Forward: the flash kernel up to 64 channels, the row kernel beyond; backward: the row / column
+    passes of hdiff_mha_wide_bwd at any width (probabilities recomputed)."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        qkv = qkv.contiguous()
+        lib = _capi.lib()
+        B, C3, H, W = (int(v) for v in qkv.shape)
+        Cc, L = C3 // 3, H * W
+        o = torch.empty(B, Cc, H, W, device=qkv.device)
+        if Cc <= 64:
+            _capi.check(lib.hdiff_mha_flash_fwd(qkv.data_ptr(), o.data_ptr(), None, B, Cc, 1, L, _stream(qkv.device)), "mha_flash_fwd")
+        else:
+            _capi.check(lib.hdiff_mha_wide_fwd(qkv.data_ptr(), o.data_ptr(), B, Cc, L, _stream(qkv.device)), "mha_wide_fwd")
+        ctx.save_for_backward(qkv)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        (qkv,) = ctx.saved_tensors
+        d_o = d_o.contiguous()
+        lib = _capi.lib()
+        B, C3, H, W = (int(v) for v in qkv.shape)
+        Cc, L = C3 // 3, H * W
+        dqkv = torch.empty_like(qkv)
+        ws = torch.empty(2 * B * L, device=qkv.device)
+        _capi.check(lib.hdiff_mha_wide_bwd(qkv.data_ptr(), d_o.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), B, Cc, L,
+                                           _stream(qkv.device)), "mha_wide_bwd")
+        return dqkv
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # public entry points
 # ----------------------------------------------------------------------------------------------------------------------
 def fused_conv(x0, x1, weight, bias, gn_w=None, gn_b=None, addvec=None, residual=None, k: int = 3, drop_p: float = 0.0):
     seed = int(torch.empty((), dtype=torch.int64).random_().item()) if drop_p > 0.0 else 0
     return _FusedConv.apply(x0, x1, weight, bias, gn_w, gn_b, addvec, residual, k, float(drop_p), seed)
+
+
+def attn_block(ab, x):
+    """AttnBlock.forward (ModelCondition.py:102-120) with gradients: GroupNorm -> q, k, v as one stacked 1x1 conv -> the
+    single-head core -> 1x1 proj with the residual x in its epilogue."""
+    hn = _GNAffineFn.apply(x, ab.group_norm.weight, ab.group_norm.bias)
+    w_qkv = torch.cat([ab.proj_q.weight, ab.proj_k.weight, ab.proj_v.weight], dim=0)
+    b_qkv = torch.cat([ab.proj_q.bias, ab.proj_k.bias, ab.proj_v.bias], dim=0)
+    qkv = fused_conv(hn, None, w_qkv, b_qkv, k=1)
+    o = _SingleHeadFn.apply(qkv)
+    return fused_conv(o, None, ab.proj.weight, ab.proj.bias, residual=x, k=1)
 
 
 def embed_mlp(seq, idx):

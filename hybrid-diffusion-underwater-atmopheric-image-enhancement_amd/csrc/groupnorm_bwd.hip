@@ -28,6 +28,7 @@ __device__ __forceinline__ float dswish_times(float da, float y) {
   return da * sg * (1.0f + y * (1.0f - sg));
 }
 
+template <bool SWISH>
 __global__ __launch_bounds__(T) void gn_bwd_reduce_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int C0,
                                                           int C1, int HW, int G, const float* __restrict__ dA,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(T) void gn_bwd_reduce_kernel(const float* __restric
   float s1 = 0.f, s2 = 0.f;
   for (int i = threadIdx.x; i < HW; i += T) {
     const float xh = (xp[i] - mu) * rs;
-    const float dy = dswish_times(dp[i], fmaf(xh, ga, be));
+    const float dy = SWISH ? dswish_times(dp[i], fmaf(xh, ga, be)) : dp[i];
     s1 += dy;
     s2 = fmaf(dy, xh, s2);
   }
@@ -83,6 +84,7 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ p1, const float
   }
 }
 
+template <bool SWISH>
 __global__ __launch_bounds__(T) void gn_bwd_apply_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int C0,
                                                          int C1, int HW, int G, const float* __restrict__ dA,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(T) void gn_bwd_apply_kernel(const float* __restrict
   const float* dp = dA + (size_t)bc * HW;
   for (int i = blockIdx.y * T + threadIdx.x; i < HW; i += gridDim.y * T) {
     const float xh = (xp[i] - mu) * rs;
-    const float dy = dswish_times(dp[i], fmaf(xh, ga, be));
+    const float dy = SWISH ? dswish_times(dp[i], fmaf(xh, ga, be)) : dp[i];
     op[i] = rs * (ga * dy - m1 - xh * m2);
   }
 }
@@ -152,29 +154,47 @@ __global__ void batch_sum_kernel(const float* __restrict__ dvec, int B, int C, f
 
 }  // namespace
 
+namespace {
+template <bool SWISH>
+int gn_bwd_launch(const float* x0, const float* x1, int C0, int C1, int B, int HW, int G, const float* dA, const float* mean,
+                  const float* rstd, const float* gamma, const float* beta, float* ws, float* dx0, float* dx1, float* dgamma,
+                  float* dbeta, hipStream_t s) {
+  const int C = C0 + C1;
+  float* p1 = ws;                 // [B][C]
+  float* p2 = ws + (size_t)B * C; // [B][C]
+  float* gs1 = p2 + (size_t)B * C; // [B][G]
+  float* gs2 = gs1 + (size_t)B * G;
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel<SWISH>, dim3(B * C), dim3(T), 0, s, x0, x1, C0, C1, HW, G, dA, mean, rstd, gamma, beta,
+                     p1, p2);
+  const int n = (C > B * G ? C : B * G);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p1, p2, gamma, B, C, G, gs1, gs2, dgamma,
+                     dbeta);
+  const int bx = cdiv(HW, T) < 32 ? cdiv(HW, T) : 32;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel<SWISH>, dim3(B * C, bx), dim3(T), 0, s, x0, x1, C0, C1, HW, G, dA, mean, rstd, gamma,
+                     beta, gs1, gs2, dx0, dx1);
+  HDIFF_CHECK_LAUNCH("gn backward kernels");
+  return HDIFF_OK;
+}
+}  // namespace
+
 extern "C" int hdiff_gn_swish_bwd(const float* x0, const float* x1, int C0, int C1, int B, int HW, int G, const float* dA,
                                   const float* mean, const float* rstd, const float* gamma, const float* beta, float* ws,
                                   float* dx0, float* dx1, float* dgamma, float* dbeta, hdiff_stream_t stream) {
   HDIFF_CHECK_ARG(x0 && dA && mean && rstd && gamma && beta && ws && dx0 && dgamma && dbeta, "gn_swish_bwd: null pointer");
   HDIFF_CHECK_ARG(C1 == 0 || (x1 && dx1), "gn_swish_bwd: C1 > 0 without x1/dx1");
-  const int C = C0 + C1;
-  HDIFF_CHECK_ARG(G > 0 && C % G == 0 && B > 0 && HW > 0, "gn_swish_bwd: bad sizes");
-  float* p1 = ws;                 // [B][C]
-  float* p2 = ws + (size_t)B * C; // [B][C]
-  float* gs1 = p2 + (size_t)B * C; // [B][G]
-  float* gs2 = gs1 + (size_t)B * G;
-  hipStream_t s = (hipStream_t)stream;
-  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * C), dim3(T), 0, s, x0, x1, C0, C1, HW, G, dA, mean, rstd, gamma, beta, p1,
-                     p2);
-  const int n = (C > B * G ? C : B * G);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p1, p2, gamma, B, C, G, gs1, gs2, dgamma,
-                     dbeta);
-  const int bx = cdiv(HW, T) < 32 ? cdiv(HW, T) : 32;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C, bx), dim3(T), 0, s, x0, x1, C0, C1, HW, G, dA, mean, rstd, gamma, beta,
-                     gs1, gs2, dx0, dx1);
-  HDIFF_CHECK_LAUNCH("gn_swish_bwd kernels");
-  return HDIFF_OK;
+  HDIFF_CHECK_ARG(G > 0 && (C0 + C1) % G == 0 && B > 0 && HW > 0, "gn_swish_bwd: bad sizes");
+  return gn_bwd_launch<true>(x0, x1, C0, C1, B, HW, G, dA, mean, rstd, gamma, beta, ws, dx0, dx1, dgamma, dbeta,
+                             (hipStream_t)stream);
+}
+
+extern "C" int hdiff_gn_affine_bwd(const float* x, int C, int B, int HW, int G, const float* dY, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, float* ws, float* dx, float* dgamma,
+                                   float* dbeta, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(x && dY && mean && rstd && gamma && beta && ws && dx && dgamma && dbeta, "gn_affine_bwd: null pointer");
+  HDIFF_CHECK_ARG(G > 0 && C > 0 && C % G == 0 && B > 0 && HW > 0, "gn_affine_bwd: bad sizes");
+  return gn_bwd_launch<false>(x, nullptr, C, 0, B, HW, G, dY, mean, rstd, gamma, beta, ws, dx, nullptr, dgamma, dbeta,
+                              (hipStream_t)stream);
 }
 
 extern "C" int hdiff_bias_addvec_grad(const float* dy, int B, int C, int HW, float* dvec, float* dbias,

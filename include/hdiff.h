@@ -168,6 +168,11 @@ int hdiff_gn_scale_shift(const float* x0, const float* x1, int C0, int C1, int B
 int hdiff_gn_swish_bwd(const float* x0, const float* x1, int C0, int C1, int B, int HW, int G, const float* dA,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, float* ws, float* dx0,
                        float* dx1, float* dgamma, float* dbeta, hdiff_stream_t stream);
+/* The same for GroupNorm WITHOUT Swish (AttnBlock's pre-norm, ModelCondition.py:103): dY is the gradient w.r.t. the
+ * normalised tensor [B][C][HW].  ws: 2*B*C + 2*B*G floats. */
+int hdiff_gn_affine_bwd(const float* x, int C, int B, int HW, int G, const float* dY, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, float* ws, float* dx, float* dgamma, float* dbeta,
+                        hdiff_stream_t stream);
 /* dvec[b][c] = sum_hw dy[b][c][:] (gradient of the per-sample channel vector) and dbias[c] = sum_b dvec[b][c]; either may be NULL */
 int hdiff_bias_addvec_grad(const float* dy, int B, int C, int HW, float* dvec, float* dbias, hdiff_stream_t stream);
 /* y = x*scale[b][c] + shift[b][c]: GroupNorm without Swish (AttnBlock, ModelCondition.py:103) */
@@ -197,6 +202,9 @@ int hdiff_mha_flash_fwd_ws(const float* qkv, float* o, float* lse2 /*[B][heads][
  * reference's AttnBlock (ModelCondition.py:109-116; dead code there, built for completeness: one workgroup per query row,
  * L + C floats of LDS).  qkv [B][3C][L] rows [q | k | v], o [B][C][L].  Heads of width <= 64: hdiff_mha_flash_fwd, heads = 1. */
 int hdiff_mha_wide_fwd(const float* qkv, float* o, int B, int C, int L, hdiff_stream_t stream);
+/* Backward of the single-head core of any width (autograd through AttnBlock.forward, ModelCondition.py:109-116): dqkv
+ * [B][3C][L] from dO [B][C][L]; probabilities are recomputed.  ws: 2*B*L floats (log-sum-exp and delta per query). */
+int hdiff_mha_wide_bwd(const float* qkv, const float* d_o, float* dqkv, float* ws, int B, int C, int L, hdiff_stream_t stream);
 /* Backward of the core (autograd of nn.MultiheadAttention, TrainCondition.py:60): dqkv [B][3C][L] from dO [B][C][L].
  * lse2 is the forward's log2-domain log-sum-exp; delta is a [B][heads][L] workspace (rowsum(dO o O), written here).
  * P is recomputed, never stored; five MFMA products per tile in ONE kernel: a workgroup owns a key range (dK, dV in

@@ -297,5 +297,39 @@ def test_attn_block_against_golden():
         e = maxerr(y, T(d[f"{name}/y"]))
         print(f"AttnBlock {name}: max err {e:.3e}")
         assert e < 5e-5, (name, e)
-    with pytest.raises(NotImplementedError):
-        ab.train()(T(d["c128/x"]).to(DEV))          # inference only (dead code in the reference)
+
+
+def test_attn_block_backward_against_the_pinned_oracle():
+    """AttnBlock with gradients (ModelCondition.py:92-120 under autograd): input and all ten parameter gradients of both golden
+    blocks against the CPU oracle differentiated by torch autograd in float64 -- that oracle's forward is pinned to the real
+    reference by attnblock.npz (test_oracle_golden.py and the test above)."""
+    from oracle import cpu_path as O
+    d = load("attnblock.npz")
+    for name in ("c64", "c128"):
+        cin = int(d[f"{name}/meta"][0])
+        sd = sd_from(d, f"{name}/sd/")
+        ab = MC.AttnBlock(cin)
+        ab.load_state_dict(sd, strict=True)
+        ab = ab.to(DEV).train()
+        x = T(d[f"{name}/x"])
+        g = torch.Generator().manual_seed(cin)
+        gy = torch.randn(x.shape, generator=g)
+        # float64 reference
+        sd64 = {"a." + k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+        x64 = x.double().clone().requires_grad_(True)
+        (O.attn_block(sd64, "a", x64) * gy.double()).sum().backward()
+        # HIP path
+        xd = x.to(DEV).requires_grad_(True)
+        y = ab(xd)
+        e = maxerr(y, T(d[f"{name}/y"]))
+        assert e < 5e-5, (name, e)
+        (y * gy.to(DEV)).sum().backward()
+        checks = [("x", xd.grad, x64.grad)] + [(k, p.grad, sd64["a." + k].grad) for k, p in ab.named_parameters()]
+        assert len(checks) == 11
+        for key, got, ref in checks:
+            assert got is not None, key
+            err, mag = maxerr(got, ref.float()), ref.abs().max().item()
+            print(f"AttnBlock {name} d{key}: max err {err:.2e} (ref max {mag:.2e})")
+            # absolute floor: the gradient of proj_k.bias is exactly zero (a constant added to every key's score cancels in
+            # the softmax), so its float64 reference is rounding noise
+            assert err <= 1e-4 * mag + 1e-6, (name, key, err, mag)
