@@ -517,7 +517,7 @@ void launch_fused(const BwdArgs& a, const BwdGeom& g, int B, int heads, hipStrea
 template <int D>
 int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* lse2, float* delta, float* dqkv, float* ws,
                int B, int C, int heads, int L, hipStream_t stream) {
-  if constexpr (D == 16) {
+  if constexpr (D == 16 || D == 32) {
     if (mha_bwd_x3_applicable(B, C, heads, L)) {       // bf16x3 mode: all five products on the bf16 matrix core
       HDIFF_CHECK_ARG(ws != nullptr, "mha_flash_bwd: this shape needs a workspace (hdiff_mha_flash_bwd_workspace)");
       const int total = B * heads * L;
@@ -571,7 +571,7 @@ extern "C" int hdiff_mha_flash_bwd_workspace(int B, int C, int heads, int L, int
   *n_floats = (g.nsplit > 1) ? (int64_t)g.nsplit * B * C * L : 0;
   // The answer does not depend on the contraction mode: a caller that sizes the buffer, switches the mode and then calls
   // must not overrun it (the call takes no size).  Shapes the split-bf16 kernel covers get the larger of the two needs.
-  if (C / heads == 16 && mha_bwd_x3_shape_ok(B, C, heads, L)) {
+  if (mha_bwd_x3_shape_ok(B, C, heads, L)) {
     const int64_t x3 = mha_bwd_x3_workspace_floats(B, C, heads, L);
     if (x3 > *n_floats) *n_floats = x3;
   }

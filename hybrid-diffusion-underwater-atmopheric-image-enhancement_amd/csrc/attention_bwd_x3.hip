@@ -36,21 +36,33 @@ namespace {
 #define X3B_ABL 0            // dev: timing ablations (bit mask), results are wrong with any bit set
 #endif
 constexpr int THREADS = 256;
-constexpr int TQ = 64;                 // queries per staged tile (two subtiles of 32 = one contraction of the q-summed products)
 constexpr int KB = 128;                // keys per workgroup block (32 per wave)
-constexpr int RROW = 32;               // bytes per query row of a piece tile: NO padding -- with ds_read_b128's real lane groups
-                                       // ({0-3, 12-15, 20-27}, ...) the plain 32-byte rows are conflict-free for the row reads,
-                                       // the transposed reads and the staging stores alike (48-byte rows: a third of all LDS
-                                       // cycles were bank conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.35)
-constexpr int RPART = TQ * RROW;       // 2048
-constexpr int QA_OFF = 0, OA_OFF = 3 * RPART;
-constexpr int SL_OFF = 6 * RPART, SD_OFF = SL_OFF + TQ * 4, BUFB = SD_OFF + TQ * 4;     // 12800 bytes
 constexpr int SROW = 72;               // bytes per key row of the dS image [key][32 queries] (64 + 8: conflict-free ds_write_b64)
 constexpr int SPART = 32 * SROW;       // 2304 per piece
 constexpr int SCRB = 3 * SPART;        // 6912 per wave
-constexpr int DQS = TQ + 4;            // row stride (floats) of a wave's dQ partial tile [16][DQS], aliased on its scratch
-static_assert(16 * DQS * 4 <= SCRB, "dQ partial tile must fit in the wave's scratch");
-static_assert(2 * BUFB + 4 * SCRB <= 65536, "static LDS");
+
+// Geometry by head width.  d 16: tiles of 64 queries (two subtiles of 32 = one contraction of the q-summed products), rows of
+// 32 bytes -- with ds_read_b128's real lane groups ({0-3, 12-15, 20-27}, ...) plain 32-byte rows are conflict-free for the row
+// reads, the transposed reads and the staging stores alike (48-byte rows: a third of all LDS cycles were bank conflicts,
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.35).  d 32: tiles of 32 queries, rows of 64 bytes, two 16-row M tiles in the
+// products whose output rows are d.
+template <int D>
+struct Geo {
+  static constexpr int TQ = (D == 16) ? 64 : 32;      // queries per staged tile
+  static constexpr int NSUB = TQ / 32;                // subtiles of 32 queries
+  static constexpr int MT = D / 16;                   // 16-row M tiles of dV^T, dK^T, dQ^T
+  static constexpr int GROW = 2 * D;                  // bytes per query row of a piece tensor in memory
+  static constexpr int RROW = GROW;                   // ... and in LDS: no padding (d 32: rows padded to 96 bytes, conflict-free for
+                                                      // row and transposed reads alike, measured no faster: 16.39 vs 16.35 ms)
+  static constexpr int CPR = GROW / 16;               // 16-byte chunks per row
+  static constexpr int RPART = TQ * RROW;
+  static constexpr int QA_OFF = 0, OA_OFF = 3 * RPART;
+  static constexpr int SL_OFF = 6 * RPART, SD_OFF = SL_OFF + TQ * 4, BUFB = SD_OFF + TQ * 4;
+  static constexpr int DQS = TQ + 4;                  // row stride (floats) of a wave's dQ partial tile [D][DQS], aliased on its scratch
+  static_assert(TQ * GROW == 2048, "staging geometry: 128 chunks per piece");
+  static_assert(D * DQS * 4 <= SCRB, "dQ partial tile must fit in the wave's scratch");
+  static_assert(2 * BUFB + 4 * SCRB <= 65536, "static LDS");
+};
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -95,17 +107,17 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 __device__ constexpr int TERM_A[6] = {0, 1, 0, 2, 1, 0};
 __device__ constexpr int TERM_B[6] = {0, 0, 1, 0, 1, 2};
 
-// piece tensors of one (sample, head), each 3 pieces of L * 16 bf16
+// piece tensors of one (sample, head), each 3 pieces of L * D bf16
 enum { T_QA = 0, T_KB = 1, T_KT = 2, T_VB = 3, T_OA = 4, T_COUNT = 5 };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // fp32 qkv [B][3C][L] and dO [B][C][L] -> the five piece tensors.  grid (L / 256, 4 * heads, B): blockIdx.y / heads
-// selects Q, K, V or dO.  Row layout: thread = one position, all 16 channels (coalesced reads, 32 contiguous bytes per
+// selects Q, K, V or dO.  Row layout: thread = one position, all D channels (coalesced reads, 2 D contiguous bytes per
 // thread and piece); transposed layout: thread = two neighbouring positions of each channel.
 // ---------------------------------------------------------------------------------------------------------------------
+template <int D>
 __global__ __launch_bounds__(THREADS) void mha_bwd_split3_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                                  __bf16* __restrict__ ws, int C, int L, float qscale) {
-  constexpr int D = 16;
   const int heads = C / D;
   const int which = blockIdx.y / heads, head = blockIdx.y - which * heads, b = blockIdx.z;
   const float* src = (which < 3) ? qkv + ((size_t)b * 3 * C + (size_t)which * C + (size_t)head * D) * L
@@ -128,8 +140,8 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_split3_kernel(const float* __
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         u32x4* o = reinterpret_cast<u32x4*>(dst + p * piece + (size_t)l * D);
-        o[0] = u32x4{h[p][0], h[p][1], h[p][2], h[p][3]};
-        o[1] = u32x4{h[p][4], h[p][5], h[p][6], h[p][7]};
+#pragma unroll
+        for (int j = 0; j < D / 8; ++j) o[j] = u32x4{h[p][4 * j], h[p][4 * j + 1], h[p][4 * j + 2], h[p][4 * j + 3]};
       }
     }
   }
@@ -162,8 +174,14 @@ struct BwdX3Args {
   float inv_sqrt_d;
 };
 
+template <int D>
 __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args a) {
-  constexpr int D = 16;
+  using G = Geo<D>;
+  constexpr int TQ = G::TQ, NSUB = G::NSUB, MT = G::MT, RROW = G::RROW, GROW = G::GROW, CPR = G::CPR, RPART = G::RPART, BUFB = G::BUFB, DQS = G::DQS;
+  constexpr int QA_OFF = G::QA_OFF, OA_OFF = G::OA_OFF, SL_OFF = G::SL_OFF, SD_OFF = G::SD_OFF;
+  constexpr int TPM = 32 / D;                  // terms per d-contracted MFMA: d 16 packs two piece products along the 32 slots
+  constexpr int NQK = 6 / TPM;                 // MFMAs of one 16x16 score tile
+  constexpr int NOP = (D == 16) ? 3 : 3;       // operand registers per 16 rows of a d-contracted operand (sets at d 16, pieces at d 32)
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB + 4 * SCRB];
 
   const int C = a.C, L = a.L;
@@ -183,12 +201,13 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
   const int kb_begin = split * a.kb_per_split;
   const int kb_end = (kb_begin + a.kb_per_split < nkb_total) ? kb_begin + a.kb_per_split : nkb_total;
 
-  // contraction slots of this lane in the d-contracted products: 8 consecutive d of one of the MFMA's two terms
-  const int doff = 8 * (g & 1);
-  const bool hi = g >> 1;
+  // contraction slots of this lane in the d-contracted products.  d 16: 8 consecutive d of one of the MFMA's two terms;
+  // d 32: 8 consecutive d of the one term
+  const int doff = (D == 16) ? 8 * (g & 1) : 8 * g;
+  const bool hi = (D == 16) && (g >> 1);
 
   // ---- staging of one query tile: 768 chunks of 16 bytes (the row pieces of Q and dO), three per thread; -lse2 and
-  // -delta by the first 128 threads
+  // -delta by the first 2 TQ threads
   unsigned goff[3];
   int lds_off[3];
 #pragma unroll
@@ -196,17 +215,17 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
     const int c = i * THREADS + tid;
     const int sel = c / 384, cv = c - sel * 384;           // 0: Q rows, 1: dO rows
     const int p = cv >> 7, rem = cv & 127;
-    const int row = rem >> 1, half = rem & 1;
-    goff[i] = (unsigned)(((sel == 0 ? T_QA : T_OA) * 3 + p) * piece_n * 2) + row * 32 + half * 16;
-    lds_off[i] = (sel == 0 ? QA_OFF : OA_OFF) + p * RPART + row * RROW + half * 16;
+    const int row = rem / CPR, ch = rem % CPR;
+    goff[i] = (unsigned)(((sel == 0 ? T_QA : T_OA) * 3 + p) * piece_n * 2) + row * GROW + ch * 16;
+    lds_off[i] = (sel == 0 ? QA_OFF : OA_OFF) + p * RPART + row * RROW + ch * 16;
   }
   const unsigned char* wsb = reinterpret_cast<const unsigned char*>(wsh);
-  const float* ldsrc = (tid < TQ) ? lbase + tid : dbase + (tid & (TQ - 1));     // used by the first 128 threads only
+  const float* ldsrc = (tid < TQ) ? lbase + tid : dbase + (tid & (TQ - 1));     // used by the first 2 TQ threads only
   u32x4 stage[3];
   float stage_ld = 0.f;
   auto stage_load = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) stage[i] = *reinterpret_cast<const u32x4*>(wsb + goff[i] + (size_t)t * (TQ * 32));
+    for (int i = 0; i < 3; ++i) stage[i] = *reinterpret_cast<const u32x4*>(wsb + goff[i] + (size_t)t * (TQ * GROW));
     if (tid < 2 * TQ) stage_ld = ldsrc[t * TQ];      // negated when stored: nothing here may consume a load at once
   };
   auto stage_store = [&](int buf) {
@@ -217,11 +236,12 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
   };
 
   // operand addresses inside a tile buffer
-  int a1addr[3];        // row reads: the term's piece of this lane half, row i16, 16 bytes at doff
+  int a1addr[NOP];      // row reads: (d 16) the term's piece of this lane half / (d 32) piece j; row i16, 16 bytes at doff
 #pragma unroll
-  for (int j = 0; j < 3; ++j) a1addr[j] = (hi ? TERM_B[2 * j + 1] : TERM_B[2 * j]) * RPART + i16 * RROW + doff * 2;
+  for (int j = 0; j < NOP; ++j)
+    a1addr[j] = ((D == 16) ? (hi ? TERM_B[2 * j + 1] : TERM_B[2 * j]) : j) * RPART + i16 * RROW + doff * 2;
   // transposed reads of the same tiles (A operands of the products that sum over queries): lane 4q + p of a 16-lane group
-  // addresses row 4g + q (then 16 + 4g + q), columns d = 4p .. 4p + 3
+  // addresses row 4g + q (then 16 + 4g + q), columns d = 16 mt + 4p .. + 3
   const int a3addr = (4 * g + (i16 >> 2)) * RROW + 8 * (i16 & 3);
   unsigned char* scr = smem + 2 * BUFB + wave * SCRB;
   float* sdq = reinterpret_cast<float*>(scr);
@@ -229,29 +249,32 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
   const int swaddr = i16 * SROW + 8 * g;                              // + piece * SPART + kt * 16 * SROW + jq * 32
   const int sraddr = (8 * g + (i16 >> 2)) * SROW + 8 * (i16 & 3);     // + piece * SPART + jq * 32 (+ 4 * SROW: second half)
   // reduction of the tile's dQ over the four waves: thread = floats tid, 256 + tid, 512 + tid, 768 + tid of the tile's
-  // [d][64 queries] block -- every slab instruction of a wave then covers 256 contiguous bytes (with four NEIGHBOURING
-  // floats per thread the four L2 adds of a wave hit the same eight lines back to back: 95 ms of a 225 ms launch)
-  const int rd = tid >> 6, rq = tid & 63;
+  // [D][TQ] block (1024 floats either way) -- every slab instruction of a wave then covers 256 contiguous bytes (with four
+  // NEIGHBOURING floats per thread the four L2 adds of a wave hit the same eight lines back to back: 95 ms of a 225 ms launch)
 
   for (int kb = kb_begin; kb < kb_end; ++kb) {
     const int key0 = kb * KB + wave * 32;
     // ---- stationary operands of the wave's 32 keys, straight from the workspace
-    u32x4 kB[2][3], vB[2][3], kT[3];
+    u32x4 kB[2][NOP], vB[2][NOP], kT[MT][3];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int p = hi ? TERM_A[2 * j + 1] : TERM_A[2 * j];
+      for (int j = 0; j < NOP; ++j) {
+        const int p = (D == 16) ? (hi ? TERM_A[2 * j + 1] : TERM_A[2 * j]) : j;
         const size_t off = (size_t)p * piece_n + (size_t)(key0 + kt * 16 + i16) * D + doff;
         kB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)T_KB * 3 * piece_n + off);
         vB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)T_VB * 3 * piece_n + off);
       }
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-      kT[p] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(T_KT * 3 + p) * piece_n + (size_t)i16 * L + key0 + 8 * g);
-    f32x4 dKt[2], dVt[2];
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) { dKt[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVt[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int p = 0; p < 3; ++p)
+        kT[mt][p] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(T_KT * 3 + p) * piece_n + (size_t)(16 * mt + i16) * L + key0 + 8 * g);
+    f32x4 dKt[2][MT], dVt[2][MT];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { dKt[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVt[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     __syncthreads();              // the previous key block's last tile is fully consumed
     stage_load(0);
@@ -259,7 +282,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
     __syncthreads();
     if (!(X3B_ABL & 8)) stage_load(1);
 
-    // dQ goes to the key range's slab (layout [tile][d][64 queries]: 4 KB per tile, contiguous): a plain store during the
+    // dQ goes to the key range's slab (layout [tile][d][TQ queries]: 4 KB per tile, contiguous): a plain store during the
     // range's first key block, fire-and-forget L2 float adds afterwards.  Only THIS thread ever touches its four slab words,
     // in program order, so the sums are formed in a fixed order (bitwise reproducible) although the adder sits in L2 --
     // and the old value never travels to the CU: no load to wait for, half the slab bytes on the CU's memory path.
@@ -269,15 +292,15 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
       const unsigned char* tb = smem + buf * BUFB;
       float* pdst = part + (size_t)t * (D * TQ) + tid;
 
-      f32x4 dQt[2][2];
+      f32x4 dQt[NSUB][2][MT];
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
+      for (int sub = 0; sub < NSUB; ++sub) {
         const unsigned char* sb = tb + sub * 32 * RROW;
-        u32x4 qA[2][3], oA[2][3];
+        u32x4 qA[2][NOP], oA[2][NOP];
 #pragma unroll
         for (int jq = 0; jq < 2; ++jq)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) {
+          for (int j = 0; j < NOP; ++j) {
             qA[jq][j] = *reinterpret_cast<const u32x4*>(sb + QA_OFF + a1addr[j] + jq * 16 * RROW);
             oA[jq][j] = *reinterpret_cast<const u32x4*>(sb + OA_OFF + a1addr[j] + jq * 16 * RROW);
           }
@@ -287,16 +310,20 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
           negl[jq] = *reinterpret_cast<const f32x4*>(tb + SL_OFF + (32 * sub + 16 * jq + 4 * g) * 4);
           negd[jq] = *reinterpret_cast<const f32x4*>(tb + SD_OFF + (32 * sub + 16 * jq + 4 * g) * 4);
         }
-        u32x4 qT[3], oT[3];
+        // A operands of the q-summed products for M tile mt: dO^T / Q^T rows d = 16 mt .., 32 queries along the contraction
+        auto load_transposed = [&](int mt, u32x4 (&qT)[3], u32x4 (&oT)[3]) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const unsigned char* sq = sb + QA_OFF + p * RPART + a3addr;
-          const unsigned char* so = sb + OA_OFF + p * RPART + a3addr;
-          const u32x2 q0 = lds_read_tr16(sq), q1 = lds_read_tr16(sq + 16 * RROW);
-          const u32x2 o0 = lds_read_tr16(so), o1 = lds_read_tr16(so + 16 * RROW);
-          qT[p] = u32x4{q0[0], q0[1], q1[0], q1[1]};
-          oT[p] = u32x4{o0[0], o0[1], o1[0], o1[1]};
-        }
+          for (int p = 0; p < 3; ++p) {
+            const unsigned char* sq = sb + QA_OFF + p * RPART + a3addr + 32 * mt;
+            const unsigned char* so = sb + OA_OFF + p * RPART + a3addr + 32 * mt;
+            const u32x2 q0 = lds_read_tr16(sq), q1 = lds_read_tr16(sq + 16 * RROW);
+            const u32x2 o0 = lds_read_tr16(so), o1 = lds_read_tr16(so + 16 * RROW);
+            qT[p] = u32x4{q0[0], q0[1], q1[0], q1[1]};
+            oT[p] = u32x4{o0[0], o0[1], o1[0], o1[1]};
+          }
+        };
+        u32x4 qT0[3], oT0[3];
+        if (MT == 1) load_transposed(0, qT0, oT0);       // d 16: read once per subtile, used by both key tiles
 
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -304,12 +331,22 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
 #pragma unroll
           for (int jq = 0; jq < 2; ++jq) {
             f32x4 acc = negl[jq];
+            if constexpr (D == 16) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc = mfma_bf16(qA[jq][j], kB[kt][j], acc);
+              for (int j = 0; j < 3; ++j) acc = mfma_bf16(qA[jq][j], kB[kt][j], acc);
+            } else {
+#pragma unroll
+              for (int term = 5; term >= 0; --term) acc = mfma_bf16(qA[jq][TERM_B[term]], kB[kt][TERM_A[term]], acc);
+            }
             S[jq] = acc;
             acc = negd[jq];
+            if constexpr (D == 16) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc = mfma_bf16(oA[jq][j], vB[kt][j], acc);
+              for (int j = 0; j < 3; ++j) acc = mfma_bf16(oA[jq][j], vB[kt][j], acc);
+            } else {
+#pragma unroll
+              for (int term = 5; term >= 0; --term) acc = mfma_bf16(oA[jq][TERM_B[term]], vB[kt][TERM_A[term]], acc);
+            }
             dP[jq] = acc;
           }
           u32x4 Pp[3], Sp[3];
@@ -347,9 +384,14 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
             }
           }
 #pragma unroll
-          for (int term = 5; term >= 0; --term) {      // small terms first
-            dVt[kt] = mfma_bf16(oT[TERM_A[term]], Pp[TERM_B[term]], dVt[kt]);
-            dKt[kt] = mfma_bf16(qT[TERM_A[term]], Sp[TERM_B[term]], dKt[kt]);
+          for (int mt = 0; mt < MT; ++mt) {
+            u32x4 qTm[3], oTm[3];
+            if (MT > 1) load_transposed(mt, qTm, oTm);       // d 32: one M tile's operands at a time (registers)
+#pragma unroll
+            for (int term = 5; term >= 0; --term) {      // small terms first
+              dVt[kt][mt] = mfma_bf16((MT == 1 ? oT0 : oTm)[TERM_A[term]], Pp[TERM_B[term]], dVt[kt][mt]);
+              dKt[kt][mt] = mfma_bf16((MT == 1 ? qT0 : qTm)[TERM_A[term]], Sp[TERM_B[term]], dKt[kt][mt]);
+            }
           }
         }
 
@@ -364,34 +406,41 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
             const u32x2 lo = lds_read_tr16(src), hi2 = lds_read_tr16(src + 4 * SROW);
             sT[p] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
           }
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int term = 5; term >= 0; --term) acc = mfma_bf16(kT[TERM_A[term]], sT[TERM_B[term]], acc);
-          dQt[sub][jq] = acc;
+          for (int mt = 0; mt < MT; ++mt) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int term = 5; term >= 0; --term) acc = mfma_bf16(kT[mt][TERM_A[term]], sT[TERM_B[term]], acc);
+            dQt[sub][jq][mt] = acc;
+          }
         }
         asm volatile("" ::: "memory");      // the next subtile's image stores stay behind these reads (same wave: in order)
       }
 
       // the wave's partial tile [d][query] over its own scratch (its reads above are done: same wave, in order)
       if (X3B_ABL & 2) {
-        if (dQt[0][0][0] + dQt[0][1][0] + dQt[1][0][1] + dQt[1][1][1] == 12345.f) *pdst = 1.f;
+        if (dQt[0][0][0][0] + dQt[0][1][0][1] == 12345.f) *pdst = 1.f;
         stage_store(buf ^ 1);
         if (!(X3B_ABL & 8)) stage_load(t + 2 < ntiles ? t + 2 : t);
       } else {
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
           for (int jq = 0; jq < 2; ++jq)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sdq[(4 * g + r) * DQS + 32 * sub + 16 * jq + i16] = dQt[sub][jq][r];
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sdq[(16 * mt + 4 * g + r) * DQS + 32 * sub + 16 * jq + i16] = dQt[sub][jq][mt][r];
         lds_barrier();
-        const float* s0 = reinterpret_cast<const float*>(smem + 2 * BUFB) + rd * DQS + rq;
+        // thread -> floats tid + 256 r of the [D][TQ] block: row d = e / TQ, query e % TQ
         f32x4 sum;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = s0[4 * r * DQS];
+          const int e = tid + 256 * r;
+          const float* s0 = reinterpret_cast<const float*>(smem + 2 * BUFB) + (e / TQ) * DQS + (e % TQ);
+          float v = s0[0];
 #pragma unroll
-          for (int w = 1; w < 4; ++w) v += s0[4 * r * DQS + w * (SCRB / 4)];
+          for (int w = 1; w < 4; ++w) v += s0[w * (SCRB / 4)];
           sum[r] = v * a.inv_sqrt_d;
         }
         // tile t + 1 into LDS, then the loads of tile t + 2
@@ -415,38 +464,42 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_x3_kernel(const BwdX3Args 
     for (int kt = 0; kt < 2; ++kt) {
       const int key = key0 + kt * 16 + i16;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int d = 4 * g + r;
-        kout[(size_t)d * L + key] = dKt[kt][r] * 0.6931471805599453f;
-        vout[(size_t)d * L + key] = dVt[kt][r];
-      }
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = 16 * mt + 4 * g + r;
+          kout[(size_t)d * L + key] = dKt[kt][mt][r] * 0.6931471805599453f;
+          vout[(size_t)d * L + key] = dVt[kt][mt][r];
+        }
     }
   }
 }
 
-// dqkv[b][head * 16 + d][q] (Q third) = 1/sqrt(d) * sum over key ranges, in order, of the tile-major slabs
-// [split][B][heads][L / 64][16][64].  Thread = four neighbouring queries of one (d, tile).
+// dqkv[b][head * D + d][q] (Q third) = sum over key ranges, in order, of the tile-major slabs
+// [split][B][heads][L / TQ][D][TQ] (already scaled by 1/sqrt(d)).  Thread = four neighbouring queries of one (d, tile).
+template <int D>
 __global__ void mha_dq_reduce_x3_kernel(const float* __restrict__ part, float* __restrict__ dqkv, int nsplit, int C, int L,
                                         size_t split_stride) {
+  constexpr int TQ = Geo<D>::TQ, Q4 = TQ / 4;
   const int b = blockIdx.y;
   const size_t per_sample = (size_t)C * L;
   const float* src = part + (size_t)b * per_sample;
   float* dst = dqkv + (size_t)b * 3 * per_sample;
   const size_t n4 = per_sample >> 2;
+  const int tiles = L / TQ;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    // i indexes the slab in its own order: head, tile, d, 16 groups of 4 queries
+    // i indexes the slab in its own order: head, tile, d, TQ / 4 groups of 4 queries
     f32x4 acc = reinterpret_cast<const f32x4*>(src)[i];
     for (int sp = 1; sp < nsplit; ++sp) acc += reinterpret_cast<const f32x4*>(src + (size_t)sp * split_stride)[i];
-    const int q4 = (int)(i & 15), d = (int)((i >> 4) & 15);
-    const size_t ht = i >> 8;                      // head * (L / 64) + tile
-    const int tiles = L / TQ;
+    const int q4 = (int)(i % Q4), d = (int)((i / Q4) % D);
+    const size_t ht = i / ((size_t)Q4 * D);        // head * tiles + tile
     const size_t head = ht / tiles, tile = ht - head * tiles;
-    reinterpret_cast<f32x4*>(dst + (head * 16 + d) * (size_t)L + tile * TQ)[q4] = acc;
+    reinterpret_cast<f32x4*>(dst + (head * D + d) * (size_t)L + tile * TQ)[q4] = acc;
   }
 }
 
 struct X3Geom { int nkb_total, per, nsplit; };
-X3Geom x3_geometry(int B, int heads, int L) {
+X3Geom x3_geometry(int B, int heads, int L, int D) {
   X3Geom g;
   g.nkb_total = L / KB;
   int want = cdiv(1024, B * heads);                      // ~2 rounds of 2 workgroups per CU on 256 CUs
@@ -454,7 +507,7 @@ X3Geom x3_geometry(int B, int heads, int L) {
   // its Q / dO tile stream in their XCD's L2: up to 16 ranges per pair (batch 16: 567 -> 553 ms per launch; 32: 547) as
   // long as the slabs stay below 16 GiB.
   {
-    const long long per_range = (long long)B * heads * 16 * L * 4;
+    const long long per_range = (long long)B * heads * D * L * 4;
     int cap = (int)((16ll << 30) / per_range);
     int more = 16 < cap ? 16 : cap;
     if (more > want) want = more;
@@ -474,7 +527,10 @@ namespace hdiff {
 // shapes the kernel covers: at least one 128-key block per CU -- below that (one sample at L <= 1024) the split pass and the
 // slab reduce cost more than the matrix core gains (56 vs 47 us at B = 1, L = 1024; 0.62 vs 0.94 ms at B = 4, L = 4096)
 bool mha_bwd_x3_shape_ok(int B, int C, int heads, int L) {
-  return C / heads == 16 && L % 256 == 0 && L >= 512 && (int64_t)B * heads * (L / KB) >= 256;
+  const int D = C / heads;
+  static const char* e = getenv("HDIFF_BWD_X3_D32");      // dev knob: 0 = d_head 32 stays on the fp32-input kernel
+  if (D == 32 && e && atoi(e) == 0) return false;
+  return C % heads == 0 && (D == 16 || D == 32) && L % 256 == 0 && L >= 512 && (int64_t)B * heads * (L / KB) >= 256;
 }
 bool mha_bwd_x3_applicable(int B, int C, int heads, int L) {
   static const char* e = getenv("HDIFF_BWD_X3");          // dev knob: 0 = keep the fp32-input kernel in every mode
@@ -485,7 +541,7 @@ bool mha_bwd_x3_applicable(int B, int C, int heads, int L) {
 // slabs (tile-major, one per key range: even a single range goes through the reduce kernel, which restores the [C][L]
 // layout) followed by the piece tensors, in floats
 int64_t mha_bwd_x3_slab_floats(int B, int C, int heads, int L) {
-  const X3Geom g = x3_geometry(B, heads, L);
+  const X3Geom g = x3_geometry(B, heads, L, C / heads);
   return (int64_t)g.nsplit * B * C * L;
 }
 int64_t mha_bwd_x3_workspace_floats(int B, int C, int heads, int L) {
@@ -496,7 +552,8 @@ int64_t mha_bwd_x3_workspace_floats(int B, int C, int heads, int L) {
 // delta has been computed by the caller (mha_delta_kernel)
 void launch_mha_bwd_x3(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, float* ws,
                        int B, int C, int heads, int L, hipStream_t stream) {
-  const X3Geom g = x3_geometry(B, heads, L);
+  const int D = C / heads;
+  const X3Geom g = x3_geometry(B, heads, L, D);
   const size_t per_sample = (size_t)C * L;
   const int64_t slab = mha_bwd_x3_slab_floats(B, C, heads, L);
   uintptr_t pw = reinterpret_cast<uintptr_t>(ws + slab);
@@ -505,15 +562,21 @@ void launch_mha_bwd_x3(const float* qkv, const float* d_o, const float* lse2, co
   BwdX3Args a;
   a.ws = pieces; a.lse2 = lse2; a.delta = delta; a.dqkv = dqkv;
   a.C = C; a.L = L; a.kb_per_split = g.per;
-  a.inv_sqrt_d = 0.25f;
+  a.inv_sqrt_d = 1.0f / sqrtf((float)D);
   a.dq_part = ws; a.split_stride = (size_t)B * per_sample; a.batch_stride = per_sample;
-  const float qscale = 1.4426950408889634f * 0.25f;
-  hipLaunchKernelGGL(mha_bwd_split3_kernel, dim3(cdiv(L, THREADS), 4 * heads, B), dim3(THREADS), 0, stream, qkv, d_o, pieces, C,
-                     L, qscale);
-  hipLaunchKernelGGL(mha_bwd_x3_kernel, dim3(g.nsplit, heads, B), dim3(THREADS), 0, stream, a);
+  const float qscale = 1.4426950408889634f * a.inv_sqrt_d;
+  const dim3 sgrid(cdiv(L, THREADS), 4 * heads, B), grid(g.nsplit, heads, B);
   const size_t n4 = per_sample / 4;
   const int bx = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(mha_dq_reduce_x3_kernel, dim3(bx, B), dim3(256), 0, stream, ws, dqkv, g.nsplit, C, L, a.split_stride);
+  if (D == 16) {
+    hipLaunchKernelGGL(mha_bwd_split3_kernel<16>, sgrid, dim3(THREADS), 0, stream, qkv, d_o, pieces, C, L, qscale);
+    hipLaunchKernelGGL(mha_bwd_x3_kernel<16>, grid, dim3(THREADS), 0, stream, a);
+    hipLaunchKernelGGL(mha_dq_reduce_x3_kernel<16>, dim3(bx, B), dim3(256), 0, stream, ws, dqkv, g.nsplit, C, L, a.split_stride);
+  } else {
+    hipLaunchKernelGGL(mha_bwd_split3_kernel<32>, sgrid, dim3(THREADS), 0, stream, qkv, d_o, pieces, C, L, qscale);
+    hipLaunchKernelGGL(mha_bwd_x3_kernel<32>, grid, dim3(THREADS), 0, stream, a);
+    hipLaunchKernelGGL(mha_dq_reduce_x3_kernel<32>, dim3(bx, B), dim3(256), 0, stream, ws, dqkv, g.nsplit, C, L, a.split_stride);
+  }
 }
 
 }  // namespace hdiff
