@@ -1,15 +1,16 @@
-// Backward of the flash self-attention core at d_head 16 in the split-bf16 formulation (the `bf16x3` contraction mode):
+// Backward of the flash self-attention core at d_head 16 and 32 in the split-bf16 formulation (the `bf16x3` contraction mode):
 // all five products of attention_bwd.hip on v_mfma_f32_16x16x32_bf16, every fp32 operand carried as three bf16 pieces
 // (x = x0 + x1 + x2 exactly, six piece products i + j <= 2, fp32 accumulation -- the error class of an fp32 FMA chain, see
 // attention_x3.hip).  Same contract, layouts and dQ slab protocol as attention_bwd.hip (reference: autograd through
 // nn.MultiheadAttention, ModelCondition.py:189, 204-208, TrainCondition.py:60): no atomics, bitwise reproducible.
 //
-//   mha_bwd_split3_kernel   Q (pre-scaled by log2(e)/sqrt(d)), K, V, dO -> bf16 pieces, once per tensor, as rows [L][16]
-//                           (plus K^T [16][L], read once per key block): 5 piece tensors, 480 bytes per position and head.
+//   mha_bwd_split3_kernel   Q (pre-scaled by log2(e)/sqrt(d)), K, V, dO -> bf16 pieces, once per tensor, as rows
+//                           [L][D] (plus K^T [D][L], read once per key block): 5 piece tensors, 30 bytes per element.
 //   mha_bwd_x3_kernel       a workgroup owns key blocks of 128 keys (32 per wave: K, V, K^T pieces in registers as MFMA
-//                           operands) and sweeps all queries in tiles of 64 (two subtiles of 32) staged through LDS:
-//       S  = Q K^T - lse2 ,  dP = dO V^T - delta     rows = queries (registers), columns = keys (lanes); 3 MFMAs each per
-//                                                    16x16 tile (two piece products along the 32-wide contraction)
+//                           operands) and sweeps all queries in tiles of 64 (d 16: two subtiles of 32) or 32 (d 32) staged
+//                           through LDS:
+//       S  = Q K^T - lse2 ,  dP = dO V^T - delta     rows = queries (registers), columns = keys (lanes); d 16: 3 MFMAs each per
+//                                                    16x16 tile (two piece products along the 32-wide contraction), d 32: 6
 //       P = exp2(S) ; dS = P o dP ; both split in registers (v_and / v_sub / v_perm only)
 //       dV^T += dO^T P ; dK^T += Q^T dS              the packed pieces ARE the B operands (32 queries = one contraction);
 //                                                    dO^T / Q^T come from the SAME row tiles through gfx950's transposing
@@ -18,7 +19,9 @@
 //                                                    ([key][query], ds_write_b64) and read back transposed by the same
 //                                                    instruction -- no third split, no 2-byte stores
 //   dQ of a tile is summed over the four waves in a fixed order and added to the key range's slab (attention_bwd.hip).
-// Per 16x16 (query, key) tile: 15 bf16 MFMAs (240 matrix cycles) + ~210 vector cycles, against 20 fp32 MFMAs (640).
+// Per 16x16 (query, key) tile at d 16: 15 bf16 MFMAs (240 matrix cycles) + ~210 vector cycles, against 20 fp32 MFMAs (640);
+// at d 32: 30 bf16 MFMAs beside the SAME vector work, against 40 fp32 MFMAs (1280) -- two 16-row M tiles in dV^T, dK^T, dQ^T,
+// whose transposed operands are fetched one M tile at a time (registers: 256, spills only outside the tile loop).
 // (Tried and removed: the tile as a software pipeline over its four (subtile, key tile) units, the scores of unit u + 1
 // issued ahead of unit u's exp / split stream -- 141.8 against 139.4 ms on the same box; as in the forward kernels the two
 // waves of a SIMD already overlap each other's matrix and vector phases, and the longer in-order stream only adds waits.)

@@ -210,7 +210,7 @@ int hdiff_mha_wide_bwd(const float* qkv, const float* d_o, float* dqkv, float* w
  * P is recomputed, never stored; five MFMA products per tile in ONE kernel: a workgroup owns a key range (dK, dV in
  * registers) and adds its dQ tiles to the partial slab of that range in ws, summed in range order afterwards -- every slab
  * word is only ever touched by one thread, in program order: bitwise reproducible.  In the bf16x3 contraction mode at
- * d_head 16 (L a multiple of 256, >= 512) the five products run on the bf16 matrix core (attention_bwd_x3.hip); ws then
+ * d_head 16 or 32 (L a multiple of 256, >= 512) the five products run on the bf16 matrix core (attention_bwd_x3.hip); ws then
  * also holds the five bf16 piece tensors of Q, K, K^T, V, dO (30 bytes per element of a [B][C][L] tensor) and the slab
  * words after a range's first key block are accumulated by in-order L2 float adds.  hdiff_mha_flash_bwd_workspace gives
  * the size of ws in floats: a function of the shape only, large enough for either contraction mode (0: ws may be NULL). */

@@ -151,16 +151,17 @@ def test_flash_attention_backward(d, H, W, B):
     close(h.grad, r.grad.float(), rel=1e-4, abs_=2e-6, what=f"flash bwd d={d} L={H * W}")
 
 
-def test_split_bf16_attention_backward_is_another_program_fp32_class_and_reproducible():
-    """attention_bwd_x3.hip (d_head 16, bf16x3 mode): B = 4, L = 8192 gives each workgroup TWO key blocks, so the dQ slab
-    takes the plain store of the first block AND the in-order L2 float adds of the second.  The result must differ from the
+@pytest.mark.parametrize("d", [16, 32])
+def test_split_bf16_attention_backward_is_another_program_fp32_class_and_reproducible(d):
+    """attention_bwd_x3.hip (d_head 16 / 32, bf16x3 mode): B = 4, L = 8192 gives each workgroup SEVERAL key blocks, so the dQ slab
+    takes the plain store of the first block AND the in-order L2 float adds of the later ones.  The result must differ from the
     fp32-input kernel's (another program ran), sit in the same error class against float64, and repeat bit for bit."""
     import ctypes as C
     from hdiff_amd import _capi
     lib = _capi.lib()
-    heads, d, L, B = 8, 16, 8192, 4
+    heads, L, B = 8, 8192, 4
     Cc = heads * d
-    g = torch.Generator().manual_seed(11)
+    g = torch.Generator().manual_seed(11 + d)
     qkv = (torch.randn(B, 3 * Cc, L, generator=g) * 1.3).to(DEV)
     d_o = torch.randn(B, Cc, L, generator=g).to(DEV)
     s = torch.cuda.current_stream().cuda_stream
