@@ -1,0 +1,478 @@
+// Flash attention forward, split-operand form, round 4: the P.V product on fp16 PAIRS instead of bf16 triples.
+// Same contract and data layout as attention.hip / attention_x3.hip (reference: nn.MultiheadAttention core,
+// ModelCondition.py:189, 204-208); reads the pre-split workspace of attention_x3p.hip for Q and K.
+//
+// Why (profiles/r03_pmc_summary.txt, tools/h2_probe.hip): the bf16-triple kernel is bound by the SUM of its vector and matrix
+// issue time, and 5.5 of its 8 vector instructions per score split P = exp2(S) into three bf16 pieces.  fp16 carries 11
+// significand bits, so TWO pieces hold 22-23 of P's 24 bits, and gfx950 has the instructions to make them in 1.5 per value:
+//     h0 = v_cvt_pk_f16_f32(p_a, p_b)                      round-to-nearest-even pair (produces fp16 subnormals)
+//     h1.lo = v_fma_mixlo_f16(p_a, 1.0, -h0.lo)            fp32 fma (the residual is exact), ONE rounding to fp16
+//     h1.hi = v_fma_mixhi_f16(p_b, 1.0, -h0.hi)
+// (the compiler emits exactly these from the plain C below when its SLP vectoriser is off -- with it the residuals become a
+// v_pk_fma_f32, which stalls against the MFMA stream; all three issue like v_perm / v_and beside the MFMA, h2_probe part B).
+//
+//   S  = Q K^T : unchanged -- bf16 triples, six products along the MFMA's 32 contraction slots (3 MFMAs per 16x16 tile
+//                at d_head 16), chain started from -m.  An error in S is an error in the exponent: it stays at fp32 class.
+//   O += P V   : P = h0 + h1 with |P - h0 - h1| <= 2^-23 P (one fp32 ulp: the second piece keeps 11 of the residual's 12
+//                bits) or <= 2^-25 absolute (fp16 subnormal spacing 2^-24); V likewise as two fp16 pieces of V * 2^s with
+//                the power of two s chosen PER CHANNEL ROW so that max |V 2^s| lies in [2^14, 2^15) (v_split_h2_kernel; O is
+//                multiplied by 2^-s at the end, exactly).  Products kept: h0 v0, h0 v1, h1 v0 (each exact in the fp32
+//                accumulator); dropped: h1 v1 <= 2^-22 |P V|.  So every product P_k V_k enters with a relative error of a
+//                few 2^-23 -- random in sign (round to nearest) -- where the fp32-MFMA kernel rounds its RUNNING SUM to
+//                2^-24 at every k-step: over L >= 512 keys the chain's error is the larger one.  tools/h2_sim.py emulates
+//                both against float64; tests/test_gpu_ops.py holds this kernel to the same gate as the bf16 triples (error
+//                against float64 <= 1.25x rms / 2x max of the fp32-MFMA kernel's), also for peaked rows, rows whose
+//                maximum moves by 2^40 along the keys, and V channels spanning 2^30.
+//   range     : fp16 ends at 65504, so the fixed softmax reference of the fp32 / bf16 kernels (first key tile's maximum,
+//                never moved, overflow -> NaN -> check pass) is not enough.  Here m starts as (first tile's maximum - 8),
+//                i.e. that maximum enters as P = 2^8, and MOVES when needed: every stage compares the sum of the 16 P values
+//                a lane has just made against 2^15 (they are >= 0, so a smaller sum means every one of them is below 2^15);
+//                a wave in which any lane trips recomputes that stage from its S accumulators (still in registers) under
+//                the new reference max - 8, after scaling O and l by the exact power of two.  One add, one compare and one
+//                scalar branch per 16 scores; the rare path costs a few hundred cycles per moved maximum.
+//                l >= 2^8 at the end (the element that set the last reference contributes 2^8), so the absolute 2^-25
+//                floor of small P values is <= 2^-33 l per element.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+using namespace hdiff;
+
+namespace {
+
+#ifndef H2_VALU_PER_STAGE
+#define H2_VALU_PER_STAGE 54
+#endif
+constexpr int KT = 64;
+constexpr int THREADS = 256;
+constexpr float OVERFLOW_LIMIT = 1.2379400e27f;   // 2^90: only NaN / inf inputs get here (the reference moves before fp16 overflows)
+constexpr float P_SHIFT = 8.0f;                   // the reference point enters as P = 2^8
+constexpr float P_TRIP = 32768.0f;                // per-lane sum of one stage's 16 P values that moves the reference
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// (a, b) -> two packed fp16 pairs with a = h0.lo + h1.lo up to 2^-23 |a| (or 2^-25 absolute), b likewise in the high halves.
+// `one` is 1.0f in a register the compiler cannot see through: fma(a, 1, -h) must stay an fma (v_fma_mixlo_f16), a - h
+// would be a conversion and a subtraction.
+__device__ __forceinline__ void split2(float a, float b, float one, unsigned& h0, unsigned& h1) {
+  const f16x2 p = {(_Float16)a, (_Float16)b};                 // v_cvt_pk_f16_f32: round to nearest even
+  unsigned u = __builtin_bit_cast(unsigned, p);
+  asm("" : "+v"(u));                                          // the halves are read back out of the packed register
+  const f16x2 q = __builtin_bit_cast(f16x2, u);
+  const f16x2 r = {(_Float16)__builtin_fmaf(a, one, -(float)q[0]), (_Float16)__builtin_fmaf(b, one, -(float)q[1])};
+  h0 = u;
+  h1 = __builtin_bit_cast(unsigned, r);
+}
+
+// split-product terms of Q K^T (piece of K, piece of Q): all i + j <= 2, as in attention_x3.hip
+__device__ constexpr int TERM_A[6] = {0, 1, 0, 2, 1, 0};
+__device__ constexpr int TERM_B[6] = {0, 0, 1, 0, 1, 2};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// V of qkv [B][3C][L] (fp32)  ->  two fp16 pieces of V * 2^s, s per channel row, in the V region of the pre-split workspace:
+// per (sample, head)  Vh[2][D][L] (fp16) at piece slot 6, and the D factors 2^-s (fp32) at piece slot 8.
+// One workgroup per (sample, channel) row: a maximum pass, then the split pass (the row comes back from L2).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(THREADS) void v_split_h2_kernel(const float* __restrict__ qkv, __bf16* __restrict__ ws, int C, int L,
+                                                             float one) {
+  const int heads = C / D;
+  const int row = blockIdx.x, head = row / D, d = row - head * D, b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const float* src = qkv + ((size_t)b * 3 * C + 2 * (size_t)C + row) * L;
+  const size_t piece = (size_t)L * D;
+  __bf16* pair = ws + ((size_t)b * heads + head) * 9 * piece;
+  _Float16* dst = reinterpret_cast<_Float16*>(pair + 6 * piece) + (size_t)d * L;
+  __shared__ float red[THREADS / 64];
+
+  float amax = 0.f;
+  for (int i = tid; i < L / 4; i += THREADS) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * (size_t)i);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  // 2^s with max |v| 2^s in [2^14, 2^15); exponent clamped so that both 2^s and 2^-s are normal numbers (an all-zero or
+  // denormal row is scaled by 2^114 at most, an infinite one by 2^-113: inf / NaN elements stay inf / NaN in fp16)
+  int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
+  e = e < -100 ? -100 : (e > 127 ? 127 : e);
+  const float scale = __builtin_bit_cast(float, (unsigned)(14 - e + 127) << 23);
+  if (tid == 0) reinterpret_cast<float*>(pair + 8 * piece)[d] = __builtin_bit_cast(float, (unsigned)(e - 14 + 127) << 23);
+  for (int i = tid; i < L / 4; i += THREADS) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * (size_t)i);
+    unsigned a0, a1, c0, c1;
+    split2(v[0] * scale, v[1] * scale, one, a0, a1);
+    split2(v[2] * scale, v[3] * scale, one, c0, c1);
+    *reinterpret_cast<u32x2*>(dst + 4 * (size_t)i) = u32x2{a0, c0};
+    *reinterpret_cast<u32x2*>(dst + piece + 4 * (size_t)i) = u32x2{a1, c1};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D, int NQ>
+__global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf16* __restrict__ ws, float* __restrict__ out,
+                                                                      float* __restrict__ lse2, int C, int L, float one) {
+  static_assert(D == 16 || D == 32, "head dim");
+  static_assert(NQ == 4, "the stage pipeline is written for four query tiles per wave");
+  constexpr int TPM = 32 / D;              // terms per QK^T MFMA
+  constexpr int NQK = 6 / TPM;             // QK^T MFMAs per 16x16 score tile
+  constexpr int MT = D / 16;               // 16-row tiles of the output
+  constexpr int KROWB = D * 2;             // bytes per key of one K piece
+  constexpr int KPART = KT * KROWB;
+  constexpr int VROWB = KT * 2 + 8;        // bytes per d row of one V piece (+8: the 16 rows of an operand read spread over banks)
+  constexpr int VPART = D * VROWB;
+  constexpr int QB = 64 * NQ;              // queries per workgroup (4 waves x NQ tiles of 16)
+  constexpr int VBASE = 3 * KPART;
+  constexpr int BUFB = VBASE + 2 * VPART;
+  constexpr int QPART = 16 * NQ * KROWB;   // one Q piece of a wave's queries
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][BUFB];
+  __shared__ __attribute__((aligned(16))) unsigned char qmem[THREADS / 64][3 * QPART];   // Q pieces, private to each wave
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const TileId tile = xcd_tile();
+  const int head = tile.head, b = tile.b;
+  const int qblk0 = tile.x * QB + wave * (16 * NQ);
+  const int ntiles = L / KT;
+
+  // contraction slots of this lane: 8 consecutive d of one term
+  const int doff = (TPM == 2) ? 8 * (g & 1) : 8 * g;
+  const bool hi = (TPM == 2) && (g >> 1);
+
+  const size_t piece_n = (size_t)L * D;
+  const __bf16* wsq = ws + ((size_t)b * gridDim.y + head) * 9 * piece_n;
+  // Q operands live in LDS (6 KB per wave, written and read by that wave alone) and pass through ONE register set: the
+  // operand of MFMA j is reloaded for the next query tile as soon as the four MFMAs that use it have been issued --
+  // holding all four query tiles' operands costs 36 more registers, which this kernel does not have (it spilled).
+  {
+    constexpr int NQC = 3 * QPART / 16;                       // 16-byte chunks: per piece 16 * NQ rows of D * 2 bytes
+#pragma unroll
+    for (int i = 0; i < NQC / 64; ++i) {
+      const int c = i * 64 + lane, p = c / (QPART / 16), rem = c - p * (QPART / 16);
+      *reinterpret_cast<u32x4*>(&qmem[wave][p * QPART + rem * 16]) =
+          *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsq + p * piece_n + (size_t)qblk0 * D) + rem * 16);
+    }
+  }
+  int qaddr[NQK];
+#pragma unroll
+  for (int j = 0; j < NQK; ++j) {
+    const int piece = (TPM == 2) ? (hi ? TERM_B[2 * j + 1] : TERM_B[2 * j]) : TERM_B[j];
+    qaddr[j] = piece * QPART + i16 * KROWB + doff * 2;
+  }
+  u32x4 qcur[NQK];
+  auto load_q = [&](int qt, int j) { qcur[j] = *reinterpret_cast<const u32x4*>(&qmem[wave][qaddr[j] + qt * 16 * KROWB]); };
+  int kaddr[NQK];
+#pragma unroll
+  for (int j = 0; j < NQK; ++j) {
+    const int piece = (TPM == 2) ? (hi ? TERM_A[2 * j + 1] : TERM_A[2 * j]) : TERM_A[j];
+    kaddr[j] = piece * KPART + i16 * KROWB + doff * 2;
+  }
+  const int vaddr = i16 * VROWB + 8 * g;
+
+  // staging: chunk c = i * 256 + tid of the tile's 16-byte chunks (three K pieces, then two V pieces), copied as they are;
+  // the chunk count is not a multiple of 256 at d_head 16: the spare threads of the last round repeat earlier V chunks
+  constexpr int NKC = 3 * KT * D / 8, NVC = 2 * D * 8, NCH = NKC + NVC, NLD = (NCH + THREADS - 1) / THREADS;
+  static_assert(NLD * THREADS - NCH <= NVC, "staging geometry");
+  const unsigned char* gsrc[NLD];
+  int lds_off[NLD], gstep[NLD];
+  u32x4 stage[NLD];
+  {
+    const __bf16* ksp = wsq + 3 * piece_n;
+    const __bf16* vsp = wsq + 6 * piece_n;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int c = i * THREADS + tid;
+      if (c >= NCH) c -= NLD * THREADS - NCH;
+      if (c < NKC) {
+        const int p = c / (KT * D / 8), rem = c - p * (KT * D / 8);
+        gsrc[i] = reinterpret_cast<const unsigned char*>(ksp + p * piece_n) + (size_t)rem * 16;
+        lds_off[i] = p * KPART + rem * 16;
+        gstep[i] = KT * D * 2;
+      } else {
+        const int cv = c - NKC;
+        const int p = cv / (D * 8), rem = cv - p * (D * 8);
+        const int d = rem >> 3, seg = rem & 7;
+        gsrc[i] = reinterpret_cast<const unsigned char*>(vsp + p * piece_n + (size_t)d * L) + seg * 16;
+        lds_off[i] = VBASE + p * VPART + d * VROWB + seg * 16;
+        gstep[i] = KT * 2;
+      }
+    }
+  }
+  auto stage_load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      // the per-tile step is a compile-time constant for the rounds that hold only K or only V chunks
+      const int step = ((i + 1) * THREADS <= NKC) ? KT * D * 2 : (i * THREADS >= NKC ? KT * 2 : gstep[i]);
+      stage[i] = *reinterpret_cast<const u32x4*>(gsrc[i] + (size_t)t * step);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {       // two 8-byte stores for K and V chunks alike: no per-thread branch
+      unsigned char* dst = &smem[buf][lds_off[i]];
+      *reinterpret_cast<u32x2*>(dst) = u32x2{stage[i][0], stage[i][1]};
+      *reinterpret_cast<u32x2*>(dst + 8) = u32x2{stage[i][2], stage[i][3]};
+    }
+  };
+
+  f32x4 O[MT][NQ];
+  f32x4 negm4[NQ];
+  float l_run[NQ];
+#pragma unroll
+  for (int qt = 0; qt < NQ; ++qt) {
+    l_run[qt] = 0.f;
+    negm4[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) O[mt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- operands and pipeline state held in registers across tiles
+  u32x4 vop[2][MT][2];         // V of the current tile: [piece][row tile][32-key chunk]
+  u32x4 kop[4][NQK];           // K of the tile whose scores are being made: [key tile][MFMA]
+  f32x4 S[2][4];               // scores of two consecutive stages
+  u32x4 pop[2][2][2];          // P of two consecutive stages: [stage parity][piece][32-key chunk]
+  auto load_v = [&](int buf) {
+    const unsigned char* vb = smem[buf] + VBASE;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const unsigned char* src = vb + p * VPART + mt * 16 * VROWB + 64 * c + vaddr;
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(src);
+          const u32x2 hi2 = *reinterpret_cast<const u32x2*>(src + 32);
+          vop[p][mt][c] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
+        }
+  };
+  auto load_k = [&](int buf) {
+    const unsigned char* kb = smem[buf];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int j = 0; j < NQK; ++j) kop[kt][j] = *reinterpret_cast<const u32x4*>(kb + kaddr[j] + kt * 16 * KROWB);
+  };
+  // MFMA n of Q K^T for query tile qt into S[par]: the four key tiles' chains round robin (a dependent pair is 4 apart)
+  auto qk_mfma = [&](int qt, int par, int n) {
+    const int j = n >> 2, kt = n & 3;
+    S[par][kt] = mfma_bf16(kop[kt][j], qcur[j], j == 0 ? negm4[qt] : S[par][kt]);      // the chain starts from -m
+    if (kt == 3) load_q((qt + 1) % NQ, j);                    // operand j is free now: fetch it for the next query tile
+  };
+  constexpr int NPV = 6 * MT;
+  // MFMA n of O[qt] += P V with P from pop[par]: per 32-key chunk and row tile the small terms first
+  auto pv_mfma = [&](int qt, int par, int n) {
+    const int c = n / (3 * MT), r = n - c * 3 * MT, mt = r / 3, term = r - mt * 3;
+    const int pv_v = term == 0 ? 1 : 0, pv_p = term == 1 ? 1 : 0;                      // (v1, p0), (v0, p1), (v0, p0)
+    O[mt][qt] = mfma_f16(vop[pv_v][mt][c], pop[par][pv_p][c], O[mt][qt]);
+  };
+  // P = exp2(S) of one stage (16 queries x 64 keys of this wave; 16 values per lane), its two fp16 pieces packed as the
+  // B operands of P.V, and the lane's two partial row sums
+  auto exp_split = [&](int par, float& sum0, float& sum1) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const float p0 = __builtin_amdgcn_exp2f(S[par][kt][0]), p1 = __builtin_amdgcn_exp2f(S[par][kt][1]);
+      const float p2 = __builtin_amdgcn_exp2f(S[par][kt][2]), p3 = __builtin_amdgcn_exp2f(S[par][kt][3]);
+      sum0 = (kt == 0) ? p0 + p2 : sum0 + (p0 + p2);
+      sum1 = (kt == 0) ? p1 + p3 : sum1 + (p1 + p3);
+      const int c = kt >> 1, o = (kt & 1) * 2;
+      unsigned a0, a1, c0, c1;
+      split2(p0, p1, one, a0, a1);
+      split2(p2, p3, one, c0, c1);
+      pop[par][0][c][o] = a0; pop[par][1][c][o] = a1;
+      pop[par][0][c][o + 1] = c0; pop[par][1][c][o + 1] = c1;
+    }
+  };
+  auto stage_max = [&](int par) {
+    float mx = fmaxf(fmaxf(S[par][0][0], S[par][0][1]), fmaxf(S[par][0][2], S[par][0][3]));
+#pragma unroll
+    for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(S[par][kt][0], S[par][kt][1]), fmaxf(S[par][kt][2], S[par][kt][3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    return fmaxf(mx, __shfl_xor(mx, 32, 64));
+  };
+  // the rare path: some P of this stage may not fit fp16 -- move the reference of the rows concerned to (their maximum
+  // over this tile) - 8, rescale what was accumulated under the old one by the exact power of two, make P again
+  auto move_reference = [&](int qt, int par, float& sum0, float& sum1) {
+    const float over = stage_max(par) - P_SHIFT;              // S holds s - m: its maximum should sit at 8
+    const float delta = over > 1.0f ? __builtin_ceilf(over) : 0.f;
+    const float f = __builtin_amdgcn_exp2f(-delta);
+    negm4[qt] -= f32x4{delta, delta, delta, delta};
+    l_run[qt] *= f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) O[mt][qt] *= f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) S[par][kt] -= f32x4{delta, delta, delta, delta};
+    exp_split(par, sum0, sum1);
+  };
+
+  // One stage = the vector work of (tile, query tile QT): S[par] -> P pieces in pop[par] -- hand-interleaved with the
+  // MFMAs of the neighbouring stages: Q K^T for the NEXT stage (into S[par ^ 1]; for QT = 3 that is query tile 0 of the
+  // next key tile, whose K operands are in kop by then) and P V of the PREVIOUS one (pop[par ^ 1]).  The order is written
+  // out and fenced slot by slot (one MFMA, about three vector instructions): left to the scheduler the MFMAs of a stage
+  // clump, and a vector instruction only runs beside an MFMA, not instead of waiting for one.
+  auto stage_fn = [&](auto qt_tag, auto first_tag, auto pend_tag) {
+    constexpr int QT = decltype(qt_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;       // first key tile: fixes the reference point
+    constexpr bool PEND = decltype(pend_tag)::value;         // P V of the previous stage is pending
+    constexpr int par = QT & 1;
+    constexpr int qk_q = (QT + 1) % NQ, pv_q = (QT + NQ - 1) % NQ;
+    constexpr int NQKM = 4 * NQK, NM = NQKM + (PEND ? NPV : 0);
+    float sum0, sum1;
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int n = 0; n < NQKM; ++n) qk_mfma(qk_q, par ^ 1, n);
+      if constexpr (PEND)
+#pragma unroll
+        for (int n = 0; n < NPV; ++n) pv_mfma(pv_q, par ^ 1, n);
+      const float nm = P_SHIFT - stage_max(par);
+      negm4[QT] = f32x4{nm, nm, nm, nm};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) S[par][kt] += negm4[QT];
+      exp_split(par, sum0, sum1);
+    } else {
+      // the stage's vector instructions as 56 numbered steps (14 per key tile: 4 exp, 2 cvt_pk, 2 adds, 2 mixlo, 2 mixhi, 2 adds)
+      float pe[4][4], ad[4][2];
+      unsigned u[4][2];
+      _Float16 rl[4][2];
+      unsigned r2[4][2];
+      auto vstep = [&](int n) {
+        const int kt = n / 14, r = n - kt * 14;
+        if (r < 4) pe[kt][r] = __builtin_amdgcn_exp2f(S[par][kt][r]);
+        else if (r < 6) {
+          const f16x2 p = {(_Float16)pe[kt][2 * (r - 4)], (_Float16)pe[kt][2 * (r - 4) + 1]};
+          unsigned w = __builtin_bit_cast(unsigned, p);
+          asm("" : "+v"(w));
+          u[kt][r - 4] = w;
+        } else if (r < 8) ad[kt][r - 6] = pe[kt][r - 6] + pe[kt][r - 6 + 2];
+        else if (r < 10) rl[kt][r - 8] = (_Float16)__builtin_fmaf(pe[kt][2 * (r - 8)], one, -(float)__builtin_bit_cast(f16x2, u[kt][r - 8])[0]);
+        else if (r < 12) {
+          const f16x2 pr = {rl[kt][r - 10],
+                            (_Float16)__builtin_fmaf(pe[kt][2 * (r - 10) + 1], one, -(float)__builtin_bit_cast(f16x2, u[kt][r - 10])[1])};
+          unsigned w = __builtin_bit_cast(unsigned, pr);
+          asm("" : "+v"(w));              // pins v_fma_mixhi_f16 to this step
+          r2[kt][r - 10] = w;
+        } else if (r == 12) sum0 = (kt == 0) ? ad[kt][0] : sum0 + ad[kt][0];
+        else sum1 = (kt == 0) ? ad[kt][1] : sum1 + ad[kt][1];
+      };
+      constexpr int NV = 56;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        if constexpr (PEND) {          // q q p q q p ...
+          if (i % 3 == 2) pv_mfma(pv_q, par ^ 1, i / 3);
+          else qk_mfma(qk_q, par ^ 1, i - i / 3);
+        } else qk_mfma(qk_q, par ^ 1, i);
+#pragma unroll
+        for (int n = NV * i / NM; n < NV * (i + 1) / NM; ++n) vstep(n);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const int c = kt >> 1, o = (kt & 1) * 2;
+        pop[par][0][c][o] = u[kt][0]; pop[par][1][c][o] = r2[kt][0];
+        pop[par][0][c][o + 1] = u[kt][1]; pop[par][1][c][o + 1] = r2[kt][1];
+      }
+      // the pieces are pinned in front of the branch: left alone the compiler sinks the residual instructions, whose
+      // results are only read by the next stage's MFMAs, below it
+      asm volatile("" : "+v"(pop[par][0][0]), "+v"(pop[par][0][1]), "+v"(pop[par][1][0]), "+v"(pop[par][1][1]));
+      if (__builtin_amdgcn_ballot_w64(sum0 + sum1 >= P_TRIP) != 0) move_reference(QT, par, sum0, sum1);
+    }
+    l_run[QT] += sum0 + sum1;
+  };
+
+  // Key tile t (buffer t & 1).  On entry: kop = K(t), S[0] = scores of (t, query tile 0), global loads of tile t + 1 in
+  // flight; unless FIRST, vop = V(t - 1) and pop[1] = P(t - 1, 3) with its P V pending.
+  auto tile_fn = [&](auto first_tag, int t) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    using Pend = std::integral_constant<bool, !FIRST>;
+    const int buf = t & 1;
+    if constexpr (FIRST) load_v(buf);
+    stage_fn(std::integral_constant<int, 0>{}, first_tag, Pend{});
+    if constexpr (!FIRST) load_v(buf);
+    stage_fn(std::integral_constant<int, 1>{}, first_tag, std::true_type{});
+    stage_fn(std::integral_constant<int, 2>{}, first_tag, std::true_type{});
+    stage_store(buf ^ 1);                 // tile t + 1: its buffer was last read before the previous tile's barrier
+    __syncthreads();
+    stage_load((t + 2 < ntiles) ? t + 2 : ntiles - 1);
+    load_k(buf ^ 1);
+    stage_fn(std::integral_constant<int, 3>{}, first_tag, std::true_type{});
+  };
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  stage_load(ntiles > 1 ? 1 : 0);
+  load_k(0);
+#pragma unroll
+  for (int j = 0; j < NQK; ++j) load_q(0, j);
+#pragma unroll
+  for (int n = 0; n < 4 * NQK; ++n) qk_mfma(0, 0, n);
+  tile_fn(std::true_type{}, 0);
+  for (int t = 1; t < ntiles; ++t) tile_fn(std::false_type{}, t);
+#pragma unroll
+  for (int n = 0; n < NPV; ++n) pv_mfma(NQ - 1, 1, n);
+
+  float* obase = out + ((size_t)b * C + (size_t)head * D) * L;
+  const float* vinv = reinterpret_cast<const float*>(wsq + 8 * piece_n);      // 2^-s per channel of this head
+#pragma unroll
+  for (int qt = 0; qt < NQ; ++qt) {
+    float lt = l_run[qt];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const bool bad = !(lt < OVERFLOW_LIMIT);            // NaN / inf inputs: hand this query block to the fp32 kernel's check pass
+    const float inv = bad ? __builtin_nanf("") : 1.0f / lt;
+    const int q = qblk0 + qt * 16 + i16;
+    if (lse2 != nullptr && g == 0)
+      lse2[((size_t)b * gridDim.y + head) * L + q] = bad ? __builtin_nanf("") : __builtin_amdgcn_logf(lt) - negm4[qt][0];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        obase[(size_t)(mt * 16 + 4 * g + r) * L + q] = (O[mt][qt][r] * inv) * vinv[mt * 16 + 4 * g + r];
+  }
+}
+
+bool h2_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("HDIFF_PV");     // dev knob: "bf16x3" keeps the bf16-triple P.V kernels of round 3
+    v = (e && strcmp(e, "bf16x3") == 0) ? 0 : 1;
+  }
+  return v != 0;
+}
+
+}  // namespace
+
+namespace hdiff {
+
+// The fp16-pair P.V kernel on the pre-split workspace (Q, K: bf16 triples written by launch_qk_split3; V: this file).
+// Returns false when the shape is not covered or the workspace is missing (the caller then runs the bf16-triple kernels).
+bool launch_mha_fwd_h2(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
+                       int64_t ws_bytes, hipStream_t stream) {
+  const int64_t need = mha_fwd_x3p_workspace(B, C, heads, L);
+  if (!h2_enabled() || need == 0 || ws == nullptr || ws_bytes < need) return false;
+  const int D = C / heads;
+  if (D != 16) return false;
+  launch_qk_split3(qkv, ws, B, C, heads, L, qscale, stream);
+  hipLaunchKernelGGL((v_split_h2_kernel<16>), dim3(C, B), dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, 1.0f);
+  hipLaunchKernelGGL((mha_flash_fwd_h2_kernel<16, 4>), dim3(L / 256, heads, B), dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2,
+                     C, L, 1.0f);
+  return true;
+}
+
+}  // namespace hdiff

@@ -370,6 +370,14 @@ int64_t mha_fwd_x3p_workspace(int B, int C, int heads, int L) {
   return (int64_t)B * 3 * C * L * 6;
 }
 
+// Q (pre-scaled) and K alone as bf16 triples into the workspace (for attention_h2.hip, which writes its own V pieces)
+void launch_qk_split3(const float* qkv, void* ws, int B, int C, int heads, int L, float qscale, hipStream_t stream) {
+  const int D = C / heads;
+  dim3 sgrid(cdiv(L, 256), 2 * heads, B);          // blockIdx.y / heads = 0 (Q), 1 (K)
+  if (D == 16) hipLaunchKernelGGL((qkv_split3_kernel<16>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);
+  else hipLaunchKernelGGL((qkv_split3_kernel<32>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);
+}
+
 // Which kernel consumes the pre-split operands (both are exact to the same class; this is speed only, measured at
 // L = 65 536 / 16 384, tools/x3_check.py): d_head 32 -> the 32x32x16 kernel here (220 vs 197 TFLOP/s-equivalent: M = 32 = d,
 // no idle MFMA rows); d_head 16 -> the 16x16x32 kernel of attention_x3.hip reading the same workspace (at d = 16 the 32-row

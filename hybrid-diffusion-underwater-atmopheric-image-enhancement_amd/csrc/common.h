@@ -109,6 +109,10 @@ void launch_mha_bwd_x3(const float* qkv, const float* d_o, const float* lse2, co
 int64_t mha_fwd_x3p_workspace(int B, int C, int heads, int L);
 bool launch_mha_fwd_x3p(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
                         int64_t ws_bytes, hipStream_t stream);
+void launch_qk_split3(const float* qkv, void* ws, int B, int C, int heads, int L, float qscale, hipStream_t stream);
+// attention_h2.hip: P.V on fp16 pairs (Q K^T on the bf16 triples of the same workspace); false = shape not covered / no workspace
+bool launch_mha_fwd_h2(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
+                       int64_t ws_bytes, hipStream_t stream);
 bool launch_mha_fwd_x3(const float* qkv, const void* ws /* pre-split operands or NULL */, float* o, float* lse2, int B, int C,
                        int heads, int L, float qscale, hipStream_t stream);
 

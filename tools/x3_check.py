@@ -40,9 +40,17 @@ def run(mode, qkv, heads, presplit=True):
     return o
 
 
-for d, L, scale in [(16, 2048, 1.0), (16, 4096, 3.0), (32, 2048, 1.0), (32, 1024, 2.0)]:
+for d, L, scale in [(16, 2048, 1.0), (16, 4096, 3.0), (16, 4096, -1.0), (16, 8192, -2.0), (32, 2048, 1.0), (32, 1024, 2.0)]:
     g = torch.Generator().manual_seed(d + L)
-    qkv = (torch.randn(1, 3 * 8 * d, L, generator=g) * scale).cuda()
+    qkv = torch.randn(1, 3 * 8 * d, L, generator=g)
+    if scale == -1.0:       # the row maximum keeps moving: key magnitudes ramp up along the sequence
+        qkv[:, 8 * d:16 * d] *= torch.linspace(0.3, 5.0, L)
+    elif scale == -2.0:     # wide-range V channels, a few huge keys late in the sequence
+        qkv[:, 16 * d:] *= torch.exp(torch.randn(1, 8 * d, 1, generator=g) * 6) * torch.exp(torch.randn(1, 8 * d, L, generator=g) * 2)
+        qkv[:, 8 * d:16 * d, 5000:5003] *= 12.0
+    else:
+        qkv = qkv * scale
+    qkv = qkv.cuda()
     r = ref64(qkv, 8)
     for mode, name, pre in [(0, "f32        ", False), (1, "bf16x3 loop", False), (1, "bf16x3 pre ", True)]:
         o = run(mode, qkv, 8, pre).double()
