@@ -78,6 +78,118 @@ __device__ __forceinline__ void split2(float a, float b, float one, unsigned& h0
   h1 = __builtin_bit_cast(unsigned, r);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Moving the softmax reference, exactly, in the stage that needs it.  A stage whose lane sum of 16 P values reached P_TRIP
+// (so some P may not fit fp16) is made again from its S accumulators, which are still in registers, under a reference
+// that puts the row's maximum over this key tile at 2^8, after O, l and -m of that query tile have been rescaled by the
+// exact power of two.  The whole wave takes the path when one lane trips; rows that do not need it get delta = 0 and
+// the same bits as before.
+// Form: a handful of asm statements, each "branch on a saved scalar condition to code kept out of line (.subsection 1),
+// come back".  Every compiler-visible form of this branch -- if, if + tied moves, a loop -- was measured: the backend
+// structurises uniform branches too and the merge of the two paths cannot share registers across its flow blocks, which put
+// 18 register copies per stage on the common path (173 ms against 150 ms without any check at L = 65 536, batch 16).  Here the
+// common path costs one add, one compare and six scalar branches that are not taken, and the results of the rare path land
+// in the registers the common path uses (tied operands).  The hazard recogniser does not look inside asm statements: the
+// s_nop / operand order below provide the wait states themselves (transcendental -> use, cvt_pk / mixlo partial writes ->
+// use, VALU -> ds_bpermute).
+// ---------------------------------------------------------------------------------------------------------------------
+#define H2_RARE_BEGIN "s_cmp_lg_u64 %[cond], 0\n\ts_cbranch_scc1 .Lh2r_%=\n.Lh2b_%=:\n\t.subsection 1\n.Lh2r_%=:\n\t"
+#define H2_RARE_END "s_branch .Lh2b_%=\n\t.subsection 0"
+
+// the row's maximum of S (= s - m) over this stage's 64 keys and the move: delta = mx > 9 ? ceil(mx - 8) : 0
+__device__ __forceinline__ float h2_rare_delta(unsigned long long cond, const f32x4 (&S)[4], int bp16, int bp32) {
+  float delta, t, u;
+  asm volatile(H2_RARE_BEGIN
+               "v_max3_f32 %[t], %[s0], %[s1], %[s2]\n\t"
+               "v_max3_f32 %[u], %[s3], %[s4], %[s5]\n\t"
+               "v_max3_f32 %[t], %[t], %[s6], %[s7]\n\t"
+               "v_max3_f32 %[u], %[u], %[s8], %[s9]\n\t"
+               "v_max3_f32 %[t], %[t], %[s10], %[s11]\n\t"
+               "v_max3_f32 %[u], %[u], %[s12], %[s13]\n\t"
+               "v_max3_f32 %[t], %[t], %[s14], %[s15]\n\t"
+               "v_max_f32 %[t], %[t], %[u]\n\t"
+               "s_nop 1\n\t"
+               "ds_bpermute_b32 %[u], %[bp16], %[t]\n\t"
+               "s_waitcnt lgkmcnt(0)\n\t"
+               "v_max_f32 %[t], %[t], %[u]\n\t"
+               "s_nop 1\n\t"
+               "ds_bpermute_b32 %[u], %[bp32], %[t]\n\t"
+               "s_waitcnt lgkmcnt(0)\n\t"
+               "v_max_f32 %[t], %[t], %[u]\n\t"              // over the four lanes that share the query
+               "v_subrev_f32 %[u], 8.0, %[t]\n\t"
+               "v_ceil_f32 %[u], %[u]\n\t"
+               "v_cmp_lt_f32 vcc, 0x41100000, %[t]\n\t"      // 9.0 < mx
+               "v_cndmask_b32 %[d], 0, %[u], vcc\n\t"
+               H2_RARE_END
+               : [d] "=&v"(delta), [t] "=&v"(t), [u] "=&v"(u)
+               : [cond] "s"(cond), [bp16] "v"(bp16), [bp32] "v"(bp32), [s0] "v"(S[0][0]), [s1] "v"(S[0][1]), [s2] "v"(S[0][2]),
+                 [s3] "v"(S[0][3]), [s4] "v"(S[1][0]), [s5] "v"(S[1][1]), [s6] "v"(S[1][2]), [s7] "v"(S[1][3]), [s8] "v"(S[2][0]),
+                 [s9] "v"(S[2][1]), [s10] "v"(S[2][2]), [s11] "v"(S[2][3]), [s12] "v"(S[3][0]), [s13] "v"(S[3][1]),
+                 [s14] "v"(S[3][2]), [s15] "v"(S[3][3])
+               : "vcc", "scc");
+  return delta;      // defined only on the rare path; only the rare path reads it
+}
+
+// O, l *= 2^-delta; -m -= delta; the lane's row sums restart from zero
+__device__ __forceinline__ void h2_rare_rescale(unsigned long long cond, float delta, f32x4& O, f32x4& negm, float& l, float& sum0,
+                                                float& sum1) {
+  float o0 = O[0], o1 = O[1], o2 = O[2], o3 = O[3], n0 = negm[0], n1 = negm[1], n2 = negm[2], n3 = negm[3], w;
+  asm volatile(H2_RARE_BEGIN
+               "v_cvt_i32_f32 %[w], %[d]\n\t"
+               "v_sub_u32 %[w], 0, %[w]\n\t"
+               "v_ldexp_f32 %[o0], %[o0], %[w]\n\t"
+               "v_ldexp_f32 %[o1], %[o1], %[w]\n\t"
+               "v_ldexp_f32 %[o2], %[o2], %[w]\n\t"
+               "v_ldexp_f32 %[o3], %[o3], %[w]\n\t"
+               "v_ldexp_f32 %[l], %[l], %[w]\n\t"
+               "v_sub_f32 %[n0], %[n0], %[d]\n\t"
+               "v_sub_f32 %[n1], %[n1], %[d]\n\t"
+               "v_sub_f32 %[n2], %[n2], %[d]\n\t"
+               "v_sub_f32 %[n3], %[n3], %[d]\n\t"
+               "v_mov_b32 %[q0], 0\n\t"
+               "v_mov_b32 %[q1], 0\n\t"
+               H2_RARE_END
+               : [o0] "+v"(o0), [o1] "+v"(o1), [o2] "+v"(o2), [o3] "+v"(o3), [n0] "+v"(n0), [n1] "+v"(n1), [n2] "+v"(n2),
+                 [n3] "+v"(n3), [l] "+v"(l), [q0] "+v"(sum0), [q1] "+v"(sum1), [w] "=&v"(w)
+               : [cond] "s"(cond), [d] "v"(delta)
+               : "scc");
+  O = f32x4{o0, o1, o2, o3};
+  negm = f32x4{n0, n1, n2, n3};
+}
+
+// four scores of one 16-key tile again: P = exp2(S - delta), its fp16 pieces and the row sums -- the common path's
+// instructions in the common path's order, so a row with delta = 0 gets its bits back
+__device__ __forceinline__ void h2_rare_exp_split(unsigned long long cond, float delta, float one, f32x4 S, unsigned& a0, unsigned& a1,
+                                                  unsigned& r0, unsigned& r1, float& sum0, float& sum1) {
+  float p0, p1, p2, p3, t0, t1;
+  asm volatile(H2_RARE_BEGIN
+               "v_sub_f32 %[p0], %[s0], %[d]\n\t"
+               "v_sub_f32 %[p1], %[s1], %[d]\n\t"
+               "v_sub_f32 %[p2], %[s2], %[d]\n\t"
+               "v_sub_f32 %[p3], %[s3], %[d]\n\t"
+               "v_exp_f32 %[p0], %[p0]\n\t"
+               "v_exp_f32 %[p1], %[p1]\n\t"
+               "v_exp_f32 %[p2], %[p2]\n\t"
+               "v_exp_f32 %[p3], %[p3]\n\t"
+               "s_nop 1\n\t"
+               "v_cvt_pk_f16_f32 %[a0], %[p0], %[p1]\n\t"
+               "v_cvt_pk_f16_f32 %[a1], %[p2], %[p3]\n\t"
+               "v_add_f32 %[t0], %[p0], %[p2]\n\t"
+               "v_add_f32 %[t1], %[p1], %[p3]\n\t"
+               "v_fma_mixlo_f16 %[r0], %[p0], %[one], -%[a0] op_sel_hi:[0,0,1]\n\t"
+               "v_fma_mixlo_f16 %[r1], %[p2], %[one], -%[a1] op_sel_hi:[0,0,1]\n\t"
+               "v_add_f32 %[q0], %[q0], %[t0]\n\t"
+               "v_add_f32 %[q1], %[q1], %[t1]\n\t"
+               "v_fma_mixhi_f16 %[r0], %[p1], %[one], -%[a0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+               "v_fma_mixhi_f16 %[r1], %[p3], %[one], -%[a1] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+               "s_nop 1\n\t"
+               H2_RARE_END
+               : [a0] "+v"(a0), [a1] "+v"(a1), [r0] "+v"(r0), [r1] "+v"(r1), [q0] "+v"(sum0), [q1] "+v"(sum1), [p0] "=&v"(p0),
+                 [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [t0] "=&v"(t0), [t1] "=&v"(t1)
+               : [cond] "s"(cond), [d] "v"(delta), [one] "s"(one), [s0] "v"(S[0]), [s1] "v"(S[1]), [s2] "v"(S[2]), [s3] "v"(S[3])
+               : "scc");
+}
+
 // split-product terms of Q K^T (piece of K, piece of Q): all i + j <= 2, as in attention_x3.hip
 __device__ constexpr int TERM_A[6] = {0, 1, 0, 2, 1, 0};
 __device__ constexpr int TERM_B[6] = {0, 0, 1, 0, 1, 2};
@@ -235,6 +347,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
   f32x4 O[MT][NQ];
   f32x4 negm4[NQ];
   float l_run[NQ];
+  const int bp16 = (lane ^ 16) * 4, bp32 = (lane ^ 32) * 4;
 #pragma unroll
   for (int qt = 0; qt < NQ; ++qt) {
     l_run[qt] = 0.f;
@@ -270,10 +383,13 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
       for (int j = 0; j < NQK; ++j) kop[kt][j] = *reinterpret_cast<const u32x4*>(kb + kaddr[j] + kt * 16 * KROWB);
   };
   // MFMA n of Q K^T for query tile qt into S[par]: the four key tiles' chains round robin (a dependent pair is 4 apart)
-  auto qk_mfma = [&](int qt, int par, int n) {
+  // rollk >= 0: this is the last query tile of the key tile -- K operand (kt, j) is free once its MFMA has been issued
+  // and is fetched for the next key tile (buffer rollk) right behind it
+  auto qk_mfma = [&](int qt, int par, int n, int rollk = -1) {
     const int j = n >> 2, kt = n & 3;
     S[par][kt] = mfma_bf16(kop[kt][j], qcur[j], j == 0 ? negm4[qt] : S[par][kt]);      // the chain starts from -m
     if (kt == 3) load_q((qt + 1) % NQ, j);                    // operand j is free now: fetch it for the next query tile
+    if (rollk >= 0) kop[kt][j] = *reinterpret_cast<const u32x4*>(smem[rollk] + kaddr[j] + kt * 16 * KROWB);
   };
   constexpr int NPV = 6 * MT;
   // MFMA n of O[qt] += P V with P from pop[par]: per 32-key chunk and row tile the small terms first
@@ -284,19 +400,19 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
   };
   // P = exp2(S) of one stage (16 queries x 64 keys of this wave; 16 values per lane), its two fp16 pieces packed as the
   // B operands of P.V, and the lane's two partial row sums
-  auto exp_split = [&](int par, float& sum0, float& sum1) {
+  auto exp_split = [&](const f32x4 (&Sq)[4], u32x4 (&pp)[2][2], float& sum0, float& sum1) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      const float p0 = __builtin_amdgcn_exp2f(S[par][kt][0]), p1 = __builtin_amdgcn_exp2f(S[par][kt][1]);
-      const float p2 = __builtin_amdgcn_exp2f(S[par][kt][2]), p3 = __builtin_amdgcn_exp2f(S[par][kt][3]);
+      const float p0 = __builtin_amdgcn_exp2f(Sq[kt][0]), p1 = __builtin_amdgcn_exp2f(Sq[kt][1]);
+      const float p2 = __builtin_amdgcn_exp2f(Sq[kt][2]), p3 = __builtin_amdgcn_exp2f(Sq[kt][3]);
       sum0 = (kt == 0) ? p0 + p2 : sum0 + (p0 + p2);
       sum1 = (kt == 0) ? p1 + p3 : sum1 + (p1 + p3);
       const int c = kt >> 1, o = (kt & 1) * 2;
       unsigned a0, a1, c0, c1;
       split2(p0, p1, one, a0, a1);
       split2(p2, p3, one, c0, c1);
-      pop[par][0][c][o] = a0; pop[par][1][c][o] = a1;
-      pop[par][0][c][o + 1] = c0; pop[par][1][c][o + 1] = c1;
+      pp[0][c][o] = a0; pp[1][c][o] = a1;
+      pp[0][c][o + 1] = c0; pp[1][c][o + 1] = c1;
     }
   };
   auto stage_max = [&](int par) {
@@ -306,27 +422,12 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     return fmaxf(mx, __shfl_xor(mx, 32, 64));
   };
-  // the rare path: some P of this stage may not fit fp16 -- move the reference of the rows concerned to (their maximum
-  // over this tile) - 8, rescale what was accumulated under the old one by the exact power of two, make P again
-  auto move_reference = [&](int qt, int par, float& sum0, float& sum1) {
-    const float over = stage_max(par) - P_SHIFT;              // S holds s - m: its maximum should sit at 8
-    const float delta = over > 1.0f ? __builtin_ceilf(over) : 0.f;
-    const float f = __builtin_amdgcn_exp2f(-delta);
-    negm4[qt] -= f32x4{delta, delta, delta, delta};
-    l_run[qt] *= f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) O[mt][qt] *= f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) S[par][kt] -= f32x4{delta, delta, delta, delta};
-    exp_split(par, sum0, sum1);
-  };
-
   // One stage = the vector work of (tile, query tile QT): S[par] -> P pieces in pop[par] -- hand-interleaved with the
   // MFMAs of the neighbouring stages: Q K^T for the NEXT stage (into S[par ^ 1]; for QT = 3 that is query tile 0 of the
   // next key tile, whose K operands are in kop by then) and P V of the PREVIOUS one (pop[par ^ 1]).  The order is written
   // out and fenced slot by slot (one MFMA, about three vector instructions): left to the scheduler the MFMAs of a stage
   // clump, and a vector instruction only runs beside an MFMA, not instead of waiting for one.
-  auto stage_fn = [&](auto qt_tag, auto first_tag, auto pend_tag) {
+  auto stage_fn = [&](auto qt_tag, auto first_tag, auto pend_tag, int rollk = -1) {
     constexpr int QT = decltype(qt_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;       // first key tile: fixes the reference point
     constexpr bool PEND = decltype(pend_tag)::value;         // P V of the previous stage is pending
@@ -336,7 +437,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
     float sum0, sum1;
     if constexpr (FIRST) {
 #pragma unroll
-      for (int n = 0; n < NQKM; ++n) qk_mfma(qk_q, par ^ 1, n);
+      for (int n = 0; n < NQKM; ++n) qk_mfma(qk_q, par ^ 1, n, rollk);
       if constexpr (PEND)
 #pragma unroll
         for (int n = 0; n < NPV; ++n) pv_mfma(pv_q, par ^ 1, n);
@@ -344,7 +445,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
       negm4[QT] = f32x4{nm, nm, nm, nm};
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) S[par][kt] += negm4[QT];
-      exp_split(par, sum0, sum1);
+      exp_split(S[par], pop[par], sum0, sum1);
     } else {
       // the stage's vector instructions as 56 numbered steps (14 per key tile: 4 exp, 2 cvt_pk, 2 adds, 2 mixlo, 2 mixhi, 2 adds)
       float pe[4][4], ad[4][2];
@@ -375,11 +476,20 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
       for (int i = 0; i < NM; ++i) {
         if constexpr (PEND) {          // q q p q q p ...
           if (i % 3 == 2) pv_mfma(pv_q, par ^ 1, i / 3);
-          else qk_mfma(qk_q, par ^ 1, i - i / 3);
-        } else qk_mfma(qk_q, par ^ 1, i);
+          else qk_mfma(qk_q, par ^ 1, i - i / 3, rollk);
+        } else qk_mfma(qk_q, par ^ 1, i, rollk);
 #pragma unroll
         for (int n = NV * i / NM; n < NV * (i + 1) / NM; ++n) vstep(n);
         __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        // any lane with sum >= P_TRIP: some P of this stage may not fit fp16 (see above)
+        const unsigned long long cond = __builtin_amdgcn_ballot_w64(sum0 + sum1 >= P_TRIP);
+        const float delta = h2_rare_delta(cond, S[par], bp16, bp32);
+        h2_rare_rescale(cond, delta, O[0][QT], negm4[QT], l_run[QT], sum0, sum1);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          h2_rare_exp_split(cond, delta, one, S[par][kt], u[kt][0], u[kt][1], r2[kt][0], r2[kt][1], sum0, sum1);
       }
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
@@ -387,10 +497,6 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
         pop[par][0][c][o] = u[kt][0]; pop[par][1][c][o] = r2[kt][0];
         pop[par][0][c][o + 1] = u[kt][1]; pop[par][1][c][o + 1] = r2[kt][1];
       }
-      // the pieces are pinned in front of the branch: left alone the compiler sinks the residual instructions, whose
-      // results are only read by the next stage's MFMAs, below it
-      asm volatile("" : "+v"(pop[par][0][0]), "+v"(pop[par][0][1]), "+v"(pop[par][1][0]), "+v"(pop[par][1][1]));
-      if (__builtin_amdgcn_ballot_w64(sum0 + sum1 >= P_TRIP) != 0) move_reference(QT, par, sum0, sum1);
     }
     l_run[QT] += sum0 + sum1;
   };
@@ -405,11 +511,10 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
     stage_fn(std::integral_constant<int, 0>{}, first_tag, Pend{});
     if constexpr (!FIRST) load_v(buf);
     stage_fn(std::integral_constant<int, 1>{}, first_tag, std::true_type{});
-    stage_fn(std::integral_constant<int, 2>{}, first_tag, std::true_type{});
     stage_store(buf ^ 1);                 // tile t + 1: its buffer was last read before the previous tile's barrier
     __syncthreads();
     stage_load((t + 2 < ntiles) ? t + 2 : ntiles - 1);
-    load_k(buf ^ 1);
+    stage_fn(std::integral_constant<int, 2>{}, first_tag, std::true_type{}, buf ^ 1);    // K(t + 1) follows K(t) through kop
     stage_fn(std::integral_constant<int, 3>{}, first_tag, std::true_type{});
   };
 
