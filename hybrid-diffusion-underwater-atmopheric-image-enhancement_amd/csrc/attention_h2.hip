@@ -42,6 +42,9 @@ using namespace hdiff;
 
 namespace {
 
+#ifndef H2_ABL
+#define H2_ABL 0      // timing ablations (wrong results by construction; tools/README.md): 1 no workgroup barrier, 2 no rolling
+#endif                // K / Q reloads, 4 no global -> LDS staging in the loop, 8 no reference check, 16 no V reload
 #ifndef H2_VALU_PER_STAGE
 #define H2_VALU_PER_STAGE 54
 #endif
@@ -388,6 +391,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
   auto qk_mfma = [&](int qt, int par, int n, int rollk = -1) {
     const int j = n >> 2, kt = n & 3;
     S[par][kt] = mfma_bf16(kop[kt][j], qcur[j], j == 0 ? negm4[qt] : S[par][kt]);      // the chain starts from -m
+    if (H2_ABL & 2) return;
     if (kt == 3) load_q((qt + 1) % NQ, j);                    // operand j is free now: fetch it for the next query tile
     if (rollk >= 0) kop[kt][j] = *reinterpret_cast<const u32x4*>(smem[rollk] + kaddr[j] + kt * 16 * KROWB);
   };
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
         for (int n = NV * i / NM; n < NV * (i + 1) / NM; ++n) vstep(n);
         __builtin_amdgcn_sched_barrier(0);
       }
-      {
+      if (!(H2_ABL & 8)) {
         // any lane with sum >= P_TRIP: some P of this stage may not fit fp16 (see above)
         const unsigned long long cond = __builtin_amdgcn_ballot_w64(sum0 + sum1 >= P_TRIP);
         const float delta = h2_rare_delta(cond, S[par], bp16, bp32);
@@ -509,11 +513,11 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
     const int buf = t & 1;
     if constexpr (FIRST) load_v(buf);
     stage_fn(std::integral_constant<int, 0>{}, first_tag, Pend{});
-    if constexpr (!FIRST) load_v(buf);
+    if constexpr (!FIRST) if (!(H2_ABL & 16)) load_v(buf);
     stage_fn(std::integral_constant<int, 1>{}, first_tag, std::true_type{});
-    stage_store(buf ^ 1);                 // tile t + 1: its buffer was last read before the previous tile's barrier
-    __syncthreads();
-    stage_load((t + 2 < ntiles) ? t + 2 : ntiles - 1);
+    if (!(H2_ABL & 4)) stage_store(buf ^ 1);                 // tile t + 1: its buffer was last read before the previous tile's barrier
+    if (!(H2_ABL & 1)) __syncthreads();
+    if (!(H2_ABL & 4)) stage_load((t + 2 < ntiles) ? t + 2 : ntiles - 1);
     stage_fn(std::integral_constant<int, 2>{}, first_tag, std::true_type{}, buf ^ 1);    // K(t + 1) follows K(t) through kop
     stage_fn(std::integral_constant<int, 3>{}, first_tag, std::true_type{});
   };
