@@ -19,9 +19,12 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+import warnings
 
 from .. import _capi
 from .. import engine as E
+
+_WARNED_SAMPLER_GRAD = False
 
 __all__ = ["extract", "GaussianDiffusionTrainer", "GaussianDiffusionSampler"]
 
@@ -234,13 +237,20 @@ class GaussianDiffusionSampler(nn.Module):
         """``noise_by_step[time_step]`` injects the per-step z (parity tests); ``trajectory`` collects the pre-clip
         x_t after every step.  Both default to the reference behaviour."""
         x_T, labels = _gpu_input(x_T, "x_T"), _gpu_input(labels, "labels")
-        with torch.cuda.device(x_T.device):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
+            # The reference runs here too (DiffusionCondition.py:82-98) and records an autograd graph through all 2T model
+            # evaluations, which nothing in its callers ever differentiates (TrainCondition.eval samples under no_grad).
+            # The loop here is an inference loop: it runs without a graph and hands back a detached tensor -- said once.
+            global _WARNED_SAMPLER_GRAD
+            if not _WARNED_SAMPLER_GRAD:
+                _WARNED_SAMPLER_GRAD = True
+                warnings.warn("GaussianDiffusionSampler.forward was called with autograd enabled: the denoising loop runs under "
+                              "torch.no_grad() and returns a tensor without grad_fn (the reference would record a graph "
+                              "through all 2T model evaluations)", RuntimeWarning, stacklevel=2)
+        with torch.no_grad(), torch.cuda.device(x_T.device):
             return self._forward(x_T, labels, noise_by_step, trajectory)
 
     def _forward(self, x_T, labels, noise_by_step, trajectory):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
-            # the reference would build an autograd graph through T steps; sampling is an inference loop here
-            raise RuntimeError("GaussianDiffusionSampler.forward must run under torch.no_grad() (as TrainCondition.eval does)")
         lib = _capi.lib()
         B, Cx, H, W = (int(v) for v in x_T.shape)
         dev = x_T.device

@@ -523,7 +523,9 @@ int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* 
       const int total = B * heads * L;
       (void)hipGetLastError();
       hipLaunchKernelGGL(mha_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, o, d_o, delta, C, D, L, total);
-      launch_mha_bwd_x3(qkv, d_o, lse2, delta, dqkv, ws, B, C, heads, L, stream);
+      static const char* pv = getenv("HDIFF_PV");          // dev knob: "bf16x3" keeps the bf16-triple kernels of round 3
+      if (pv && strcmp(pv, "bf16x3") == 0) launch_mha_bwd_x3(qkv, d_o, lse2, delta, dqkv, ws, B, C, heads, L, stream);
+      else launch_mha_bwd_h2(qkv, d_o, lse2, delta, dqkv, ws, B, C, heads, L, stream);
       HDIFF_CHECK_LAUNCH("mha_bwd (split-bf16) kernels");
       return HDIFF_OK;
     }

@@ -104,6 +104,10 @@ bool mha_bwd_x3_applicable(int B, int C, int heads, int L);   // shape AND the b
 int64_t mha_bwd_x3_workspace_floats(int B, int C, int heads, int L);   // dQ slabs + piece tensors
 void launch_mha_bwd_x3(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, float* ws, int B,
                        int C, int heads, int L, hipStream_t stream);
+// attention_bwd_h2.hip: the same backward with P and the (dO, V) pair on fp16 pairs; shapes, workspace and slab geometry
+// are those of the bf16-triple kernel above
+void launch_mha_bwd_h2(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, float* ws, int B,
+                       int C, int heads, int L, hipStream_t stream);
 // attention_x3.hip: returns false when the shape is not covered (caller falls back to the fp32 kernels)
 // attention_x3p.hip: the same contraction on operands split ONCE into a workspace (0 bytes = shape not covered)
 int64_t mha_fwd_x3p_workspace(int B, int C, int heads, int L);

@@ -641,8 +641,20 @@ bool is_x3_conv(const hdiff_conv_desc* d) {
   const bool phase = d->out_sy == 2 && d->out_sx == 2 && (d->out_oy == 0 || d->out_oy == 1) && (d->out_ox == 0 || d->out_ox == 1) &&
                      d->OH == 2 * d->H && d->OW == 2 * d->W && d->residual == nullptr;
   if (!same && !phase) return false;
-  for (int t = 0; t < d->ntaps; ++t)
+  unsigned seen = 0;
+  for (int t = 0; t < d->ntaps; ++t) {
     if (d->tap_dy[t] < -1 || d->tap_dy[t] > 1 || d->tap_dx[t] < -1 || d->tap_dx[t] > 1) return false;
+    const unsigned bit = 1u << ((d->tap_dy[t] + 1) * 3 + (d->tap_dx[t] + 1));
+    if (seen & bit) return false;                 // a tap listed twice: not a launch any of the x3 packs describes
+    seen |= bit;
+  }
+  // the plain 3x3 pack (hdiff_pack_conv_weight_x3, forward and mirrored / transposed) stores tap t = (t / 3, t % 3): a
+  // descriptor that lists its nine taps in another order keeps the fp32 kernel, which reads the order from the descriptor.
+  // (Tap LISTS -- the transposed-conv phases -- are packed from the caller's own list by hdiff_pack_conv_weight_x3_taps;
+  // the descriptor must list the taps in that order, include/hdiff.h.)
+  if (same)
+    for (int t = 0; t < 9; ++t)
+      if (d->ntaps != 9 || d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1) return false;
   const int Cin = d->C0 + d->C1;
   if (Cin % 16 != 0 || (d->C1 != 0 && d->C0 % 16 != 0) || Cin > 4096) return false;
   const long blocks = (long)cdiv(d->W, 32) * cdiv(d->H, 8) * cdiv(d->Cout, 64) * d->B;

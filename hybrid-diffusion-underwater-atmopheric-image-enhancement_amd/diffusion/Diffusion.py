@@ -19,12 +19,16 @@ from __future__ import annotations
 import ctypes as C
 from typing import List, Optional
 
+import warnings
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _capi
 from .. import engine as E
+
+_WARNED_SAMPLER_GRAD = False
 
 __all__ = ["extract", "GaussianDiffusionSampler"]
 
@@ -137,12 +141,22 @@ class GaussianDiffusionSampler(nn.Module):
                 noise_by_step: Optional[List[torch.Tensor]] = None, trajectory: Optional[List[torch.Tensor]] = None):
         """``y_T`` / ``noise_by_step`` inject the random draws (parity runs; ``noise_by_step[k]`` is the k-th per-step draw of
         the ancestral loop, in call order); by default they come from torch's generator exactly where the reference draws
-        them.  ``trajectory`` collects the pre-clip y_t after every step."""
+        them.  ``trajectory`` collects the pre-clip y_t after every step.  Called with autograd enabled (the reference would
+        record a graph through every model evaluation, diffusion/Diffusion.py:217-269) the loop still runs without one and
+        returns a detached tensor, with one RuntimeWarning per process."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
+            global _WARNED_SAMPLER_GRAD
+            if not _WARNED_SAMPLER_GRAD:
+                _WARNED_SAMPLER_GRAD = True
+                warnings.warn("GaussianDiffusionSampler.forward was called with autograd enabled: the sampling loop runs under "
+                              "torch.no_grad() and returns a tensor without grad_fn", RuntimeWarning, stacklevel=2)
+        with torch.no_grad():
+            return self._forward(input_image, ddim, unconditional_guidance_scale, ddim_step, y_T, noise_by_step, trajectory)
+
+    def _forward(self, input_image, ddim, unconditional_guidance_scale, ddim_step, y_T, noise_by_step, trajectory):
         if input_image.is_cuda and not input_image.is_contiguous():
             input_image = input_image.contiguous()
         E.require_gpu_tensor(input_image, "input_image")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
-            raise RuntimeError("GaussianDiffusionSampler.forward must run under torch.no_grad()")
         lib = _capi.lib()
         dev = input_image.device
         img = input_image.float() / 255.0                                                          # :220

@@ -318,6 +318,13 @@ class Plan:
         raw = bytes(jobs)
         table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
         K = int(self._vec_jobs[0][0].shape[1])
+        # ONE input width serves every job and both inputs (the kernel reads K floats of temb and of cemb per row)
+        if int(temb.shape[1]) != K or (cemb is not None and int(cemb.shape[1]) != K):
+            raise RuntimeError(f"block projections: embedding width {tuple(temb.shape)} / "
+                               f"{None if cemb is None else tuple(cemb.shape)} does not match the weights' {K}")
+        for wt, _, wc, _, _ in self._vec_jobs:
+            if int(wt.shape[1]) != K or (wc is not None and int(wc.shape[1]) != K):
+                raise RuntimeError("block projections: temb_proj / cond_proj weights of different input widths in one model")
         self.keep((table, temb, cemb, list(self._vec_jobs)))
         self.ops.insert(pos, ("hdiff_linear_rows_multi", getattr(self.lib, "hdiff_linear_rows_multi"),
                               (temb.data_ptr(), _ptr(cemb), table.data_ptr(), len(self._vec_jobs), first, B, K)))

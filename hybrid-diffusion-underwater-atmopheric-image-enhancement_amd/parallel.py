@@ -210,6 +210,7 @@ class FlatGradients:
     def _make_hook(self, i: int):
         def hook(p: torch.Tensor) -> None:
             if p.grad is None or p.grad.data_ptr() != self.views[i].data_ptr():     # the view was replaced behind our back: exchange_mean_ repairs and starts it
+                self._fired[i] = True     # it DID receive a gradient: must not be learned as unused (skip_unused)
                 return
             b = self._owner[i]
             if b < self._next:

@@ -203,3 +203,76 @@ def test_plane_count_beyond_65535():
                                        rstd.contiguous().data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(),
                                        dx.data_ptr(), None, dgw.data_ptr(), dgb.data_ptr(), s), "gn_swish_bwd")
     assert (dx.double() - x64.grad).abs().max().item() < 1e-4 * x64.grad.abs().max().item()
+
+
+def test_split_bf16_conv_refuses_a_permuted_or_repeated_tap_list():
+    """include/hdiff.h (wp_x3): hdiff_pack_conv_weight_x3 stores tap t = (t / 3, t % 3).  A descriptor that lists the nine
+    taps in another order (its fp32 pack wp follows that order) must not be fed to the split-bf16 kernel, which would pair
+    the descriptor's offsets with the canonical pack -- it keeps the fp32 kernel, which reads the order from the descriptor.
+    Same for a list with a repeated tap.  (conv_igemm.hip is_x3_conv.)"""
+    import math
+    import torch.nn.functional as F
+    from hdiff_amd import engine as E
+    hdiff_amd.set_contraction_mode("bf16x3")
+    try:
+        g = torch.Generator().manual_seed(3)
+        B, Cin, Cout, H, W = 16, 64, 64, 64, 64                       # large enough for the split-bf16 kernel (>= 192 workgroups)
+        x = torch.randn(B, Cin, H, W, generator=g).cuda()
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).cuda()
+        want = F.conv2d(x.double(), w.double(), padding=1)
+
+        def run(perm, repeat=False):
+            plan = E.Plan("cuda")
+            taps = E.conv_taps(3, 1)
+            taps = E.TapSet([taps.dy[i] for i in perm], [taps.dx[i] for i in perm], [taps.ky[i] for i in perm], [taps.kx[i] for i in perm])
+            if repeat:                                               # tap 0 twice, the last one dropped: some other convolution
+                taps.dy[8], taps.dx[8], taps.ky[8], taps.kx[8] = taps.dy[0], taps.dx[0], taps.ky[0], taps.kx[0]
+            pk = E._new_pack(plan, Cout, Cin, taps)
+            pk.add_source(w, 0, taps.ky, taps.kx, 0)
+            pk.enable_x3(w)                                          # canonical three-piece pack, whatever the list says
+            out = plan.buf(B, Cout, H, W)
+            plan.conv(x, None, pk, None, out, B=B, H=H, W=W, VH=H, VW=W)
+            plan.pack_weights()
+            plan.run()
+            torch.cuda.synchronize()
+            return out.clone()
+
+        canon = run(list(range(9)))
+        perm = run([8, 0, 3, 1, 7, 2, 6, 4, 5])
+        err = lambda o: (o.double() - want).abs().max().item()
+        assert err(canon) < 2e-5 and err(perm) < 2e-5, (err(canon), err(perm))
+        assert not torch.equal(canon, perm), "the permuted list should have run the fp32-input kernel, not the split-bf16 one"
+        rep = run(list(range(9)), repeat=True)
+        w_rep = w.clone()
+        w_rep[:, :, 2, 2] = 0
+        w_rep_extra = torch.zeros_like(w)
+        w_rep_extra[:, :, 0, 0] = w[:, :, 0, 0]
+        want_rep = F.conv2d(x.double(), (w_rep + w_rep_extra).double(), padding=1)
+        assert (rep.double() - want_rep).abs().max().item() < 2e-5
+    finally:
+        hdiff_amd.set_contraction_mode("bf16x3")
+
+
+def test_sampler_runs_with_autograd_enabled_like_the_reference():
+    """The reference's sampler can be called with autograd on (DiffusionCondition.py:82-98; it then records a graph nobody
+    differentiates).  Here the loop enters torch.no_grad() itself: same values as under no_grad, a detached result, one
+    RuntimeWarning per process."""
+    import warnings
+    m = small(seed=4).cuda().eval()
+    cfg = SMALL
+    s = DC.GaussianDiffusionSampler(m, 1e-4, 0.02, cfg["T"], w=1.2).cuda()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 16, 16, generator=g).cuda()
+    lab = torch.tensor([1, 2]).cuda()
+    noise = torch.randn(cfg["T"], 2, 3, 16, 16, generator=g).cuda()
+    with torch.no_grad():
+        want = s(x, lab, noise_by_step=noise)
+    DC._WARNED_SAMPLER_GRAD = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        assert torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters())
+        got = s(x, lab, noise_by_step=noise)
+        again = s(x, lab, noise_by_step=noise)
+    assert torch.equal(got, want) and torch.equal(again, want)
+    assert not got.requires_grad and got.grad_fn is None
+    assert sum(issubclass(r.category, RuntimeWarning) and "autograd enabled" in str(r.message) for r in rec) == 1
