@@ -193,9 +193,12 @@ __device__ __forceinline__ void h2_rare_exp_split(unsigned long long cond, float
                : "scc");
 }
 
-// split-product terms of Q K^T (piece of K, piece of Q): all i + j <= 2, as in attention_x3.hip
-__device__ constexpr int TERM_A[6] = {0, 1, 0, 2, 1, 0};
-__device__ constexpr int TERM_B[6] = {0, 0, 1, 0, 1, 2};
+// split-product terms of Q K^T (piece of K, piece of Q): all i + j <= 2.  At d_head 16 two terms share one MFMA (the low
+// and the high half of its 32 contraction slots); they are paired so that MFMA 0 and MFMA 1 take the SAME K operand
+// (k0 | k1) -- against (q0 | q1) and (q1 | q0) -- and MFMA 2 takes (k0 | k2) against (q2 | q0): two K operand sets per 16
+// keys instead of three (16 registers and a third of the K reads from LDS), which is what lets Q stay in registers.
+__device__ constexpr int TERM_A[6] = {0, 1, 0, 1, 0, 2};
+__device__ constexpr int TERM_B[6] = {0, 1, 1, 0, 2, 0};
 
 // ---------------------------------------------------------------------------------------------------------------------
 // V of qkv [B][3C][L] (fp32)  ->  two fp16 pieces of V * 2^s, s per channel row, in the V region of the pre-split workspace:
@@ -244,8 +247,9 @@ __global__ __launch_bounds__(THREADS) void v_split_h2_kernel(const float* __rest
 template <int D, int NQ>
 __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf16* __restrict__ ws, float* __restrict__ out,
                                                                       float* __restrict__ lse2, int C, int L, float one) {
-  static_assert(D == 16 || D == 32, "head dim");
+  static_assert(D == 16, "head dim: the operand sharing below is that of two terms per MFMA");
   static_assert(NQ == 4, "the stage pipeline is written for four query tiles per wave");
+  constexpr int NKS = 2;                   // K operand sets per 16 keys: (k0 | k1) for MFMAs 0 and 1, (k0 | k2) for MFMA 2
   constexpr int TPM = 32 / D;              // terms per QK^T MFMA
   constexpr int NQK = 6 / TPM;             // QK^T MFMAs per 16x16 score tile
   constexpr int MT = D / 16;               // 16-row tiles of the output
@@ -256,9 +260,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
   constexpr int QB = 64 * NQ;              // queries per workgroup (4 waves x NQ tiles of 16)
   constexpr int VBASE = 3 * KPART;
   constexpr int BUFB = VBASE + 2 * VPART;
-  constexpr int QPART = 16 * NQ * KROWB;   // one Q piece of a wave's queries
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][BUFB];
-  __shared__ __attribute__((aligned(16))) unsigned char qmem[THREADS / 64][3 * QPART];   // Q pieces, private to each wave
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
@@ -273,32 +275,21 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
 
   const size_t piece_n = (size_t)L * D;
   const __bf16* wsq = ws + ((size_t)b * gridDim.y + head) * 9 * piece_n;
-  // Q operands live in LDS (6 KB per wave, written and read by that wave alone) and pass through ONE register set: the
-  // operand of MFMA j is reloaded for the next query tile as soon as the four MFMAs that use it have been issued --
-  // holding all four query tiles' operands costs 36 more registers, which this kernel does not have (it spilled).
-  {
-    constexpr int NQC = 3 * QPART / 16;                       // 16-byte chunks: per piece 16 * NQ rows of D * 2 bytes
+  // Q operands of the wave's four query tiles, in registers for the whole kernel: [query tile][MFMA]
+  u32x4 qop[NQ][NQK];
 #pragma unroll
-    for (int i = 0; i < NQC / 64; ++i) {
-      const int c = i * 64 + lane, p = c / (QPART / 16), rem = c - p * (QPART / 16);
-      *reinterpret_cast<u32x4*>(&qmem[wave][p * QPART + rem * 16]) =
-          *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wsq + p * piece_n + (size_t)qblk0 * D) + rem * 16);
-    }
-  }
-  int qaddr[NQK];
+  for (int qt = 0; qt < NQ; ++qt) {
+    const int q = qblk0 + qt * 16 + i16;
+    u32x4 piece[3];
 #pragma unroll
-  for (int j = 0; j < NQK; ++j) {
-    const int piece = (TPM == 2) ? (hi ? TERM_B[2 * j + 1] : TERM_B[2 * j]) : TERM_B[j];
-    qaddr[j] = piece * QPART + i16 * KROWB + doff * 2;
-  }
-  u32x4 qcur[NQK];
-  auto load_q = [&](int qt, int j) { qcur[j] = *reinterpret_cast<const u32x4*>(&qmem[wave][qaddr[j] + qt * 16 * KROWB]); };
-  int kaddr[NQK];
+    for (int p = 0; p < 3; ++p) piece[p] = *reinterpret_cast<const u32x4*>(wsq + p * piece_n + (size_t)q * D + doff);
 #pragma unroll
-  for (int j = 0; j < NQK; ++j) {
-    const int piece = (TPM == 2) ? (hi ? TERM_A[2 * j + 1] : TERM_A[2 * j]) : TERM_A[j];
-    kaddr[j] = piece * KPART + i16 * KROWB + doff * 2;
+    for (int j = 0; j < NQK; ++j) qop[qt][j] = hi ? piece[TERM_B[2 * j + 1]] : piece[TERM_B[2 * j]];
   }
+  int kaddr[NKS];          // K operand set s: the A operand of MFMA 2 s (and, for s = 0, of MFMA 1)
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) kaddr[ks] = (hi ? TERM_A[4 * ks + 1] : TERM_A[4 * ks]) * KPART + i16 * KROWB + doff * 2;
+  static_assert(TERM_A[0] == TERM_A[2] && TERM_A[1] == TERM_A[3], "MFMAs 0 and 1 share their K operand");
   const int vaddr = i16 * VROWB + 8 * g;
 
   // staging: chunk c = i * 256 + tid of the tile's 16-byte chunks (three K pieces, then two V pieces), copied as they are;
@@ -361,7 +352,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
 
   // ---- operands and pipeline state held in registers across tiles
   u32x4 vop[2][MT][2];         // V of the current tile: [piece][row tile][32-key chunk]
-  u32x4 kop[4][NQK];           // K of the tile whose scores are being made: [key tile][MFMA]
+  u32x4 kop[4][NKS];           // K of the tile whose scores are being made: [key tile][operand set]
   f32x4 S[2][4];               // scores of two consecutive stages
   u32x4 pop[2][2][2];          // P of two consecutive stages: [stage parity][piece][32-key chunk]
   auto load_v = [&](int buf) {
@@ -383,17 +374,16 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int j = 0; j < NQK; ++j) kop[kt][j] = *reinterpret_cast<const u32x4*>(kb + kaddr[j] + kt * 16 * KROWB);
+      for (int ks = 0; ks < NKS; ++ks) kop[kt][ks] = *reinterpret_cast<const u32x4*>(kb + kaddr[ks] + kt * 16 * KROWB);
   };
   // MFMA n of Q K^T for query tile qt into S[par]: the four key tiles' chains round robin (a dependent pair is 4 apart)
-  // rollk >= 0: this is the last query tile of the key tile -- K operand (kt, j) is free once its MFMA has been issued
-  // and is fetched for the next key tile (buffer rollk) right behind it
+  // rollk >= 0: this is the last query tile of the key tile -- a K operand set is free once its last MFMA has been issued
+  // (set 0 after MFMA 1, set 1 after MFMA 2) and is fetched for the next key tile (buffer rollk) right behind it
   auto qk_mfma = [&](int qt, int par, int n, int rollk = -1) {
-    const int j = n >> 2, kt = n & 3;
-    S[par][kt] = mfma_bf16(kop[kt][j], qcur[j], j == 0 ? negm4[qt] : S[par][kt]);      // the chain starts from -m
+    const int j = n >> 2, kt = n & 3, ks = j >> 1;
+    S[par][kt] = mfma_bf16(kop[kt][ks], qop[qt][j], j == 0 ? negm4[qt] : S[par][kt]);      // the chain starts from -m
     if (H2_ABL & 2) return;
-    if (kt == 3) load_q((qt + 1) % NQ, j);                    // operand j is free now: fetch it for the next query tile
-    if (rollk >= 0) kop[kt][j] = *reinterpret_cast<const u32x4*>(smem[rollk] + kaddr[j] + kt * 16 * KROWB);
+    if (rollk >= 0 && j >= 1) kop[kt][ks] = *reinterpret_cast<const u32x4*>(smem[rollk] + kaddr[ks] + kt * 16 * KROWB);
   };
   constexpr int NPV = 6 * MT;
   // MFMA n of O[qt] += P V with P from pop[par]: per 32-key chunk and row tile the small terms first
@@ -527,8 +517,6 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
   __syncthreads();
   stage_load(ntiles > 1 ? 1 : 0);
   load_k(0);
-#pragma unroll
-  for (int j = 0; j < NQK; ++j) load_q(0, j);
 #pragma unroll
   for (int n = 0; n < 4 * NQK; ++n) qk_mfma(0, 0, n);
   tile_fn(std::true_type{}, 0);
