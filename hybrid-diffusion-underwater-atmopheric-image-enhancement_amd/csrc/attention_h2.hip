@@ -381,7 +381,8 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
   // (set 0 after MFMA 1, set 1 after MFMA 2) and is fetched for the next key tile (buffer rollk) right behind it
   auto qk_mfma = [&](int qt, int par, int n, int rollk = -1) {
     const int j = n >> 2, kt = n & 3, ks = j >> 1;
-    S[par][kt] = mfma_bf16(kop[kt][ks], qop[qt][j], j == 0 ? negm4[qt] : S[par][kt]);      // the chain starts from -m
+    if (!((HDIFF_MUTANT & 4) && j == 2))        // (mutation test: the (k0 q2 + k2 q0) MFMA dropped)
+      S[par][kt] = mfma_bf16(kop[kt][ks], qop[qt][j], j == 0 ? negm4[qt] : S[par][kt]);      // the chain starts from -m
     if (H2_ABL & 2) return;
     if (rollk >= 0 && j >= 1) kop[kt][ks] = *reinterpret_cast<const u32x4*>(smem[rollk] + kaddr[ks] + kt * 16 * KROWB);
   };

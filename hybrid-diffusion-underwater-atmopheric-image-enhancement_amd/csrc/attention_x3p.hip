@@ -256,7 +256,8 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
 #pragma unroll
     for (int term = 0; term < 6; ++term)
 #pragma unroll
-      for (int s = 0; s < KS; ++s) S = mfma32(kop[TERM_A[term]][s], qop[G][TERM_B[term]][s], S);
+      for (int s = 0; s < KS; ++s)
+        if (!((HDIFF_MUTANT & 2) && TERM_A[term] == 0 && TERM_B[term] == 2)) S = mfma32(kop[TERM_A[term]][s], qop[G][TERM_B[term]][s], S);
     return S;
   };
   auto softmax_split = [&](const f32x16& S, int G, u32x4 (&pop)[2][3]) {

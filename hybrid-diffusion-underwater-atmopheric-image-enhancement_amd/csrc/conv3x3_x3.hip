@@ -177,7 +177,8 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   };
   auto mma_unit = [&](const u32x4 (&wa)[3], const u32x4 (&xp)[3], int nt) {
 #pragma unroll
-    for (int t = 0; t < 6; ++t) acc[nt] = mfma_bf16(wa[TERM_W[t]], xp[TERM_X[t]], acc[nt]);
+    for (int t = 0; t < 6; ++t)
+      if (!((HDIFF_MUTANT & 1) && TERM_W[t] == 0 && TERM_X[t] == 2)) acc[nt] = mfma_bf16(wa[TERM_W[t]], xp[TERM_X[t]], acc[nt]);
   };
 
   // Chunk loop, ONE barrier per chunk: while the matrix core works through chunk c (LDS buffer c & 1), the vector pipe turns

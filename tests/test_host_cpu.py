@@ -365,6 +365,14 @@ def test_launch_ranks_relays_rank0_and_propagates_failure(tmp_path):
     assert "line from rank 2 of 3" in ok.stderr
     bad = subprocess.run([os.sys.executable, "-c", code, "--x", "--fail"], capture_output=True, text=True, timeout=120)
     assert bad.returncode == 3 and "rank 1 exited with 3" in bad.stderr
+    # the size it ships at (BASELINE configs C4 / C5: one node, 8 ranks)
+    code8 = code.replace("sys.argv[1:], 3))", "sys.argv[1:], 8))")
+    ok8 = subprocess.run([os.sys.executable, "-c", code8, "--x"], capture_output=True, text=True, timeout=180)
+    assert ok8.returncode == 0, ok8.stderr
+    assert ok8.stdout.strip().splitlines() == ["line from rank 0 of 8 ['--x']"]
+    assert all(f"line from rank {r} of 8" in ok8.stderr for r in range(1, 8))
+    bad8 = subprocess.run([os.sys.executable, "-c", code8, "--x", "--fail"], capture_output=True, text=True, timeout=180)
+    assert bad8.returncode == 3 and "rank 1 exited with 3" in bad8.stderr
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():

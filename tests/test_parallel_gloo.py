@@ -2,6 +2,8 @@
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -155,3 +157,64 @@ def test_epoch_shards_are_disjoint_exhaustive_and_equal():
                 assert len(set(flat)) == len(flat)                                  # disjoint
         assert _epoch_indices(n, 0, 0, world) != _epoch_indices(n, 1, 0, world) or n < 3   # reshuffled every epoch
         assert _epoch_indices(n, 2, 0, world) == _epoch_indices(n, 2, 0, world)            # deterministic
+
+
+def _worker_world(rank, world, port, q):
+    """The exchange at the world size it ships at (BASELINE config C4: 8 ranks): a parameter count that is not a multiple of
+    the world size, one parameter outside the graph, bucketed reduce-scatters started from the gradient hooks."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, l, w = P.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(3)                               # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))      # 35 + 5 + 15 + 3 = 58 parameters
+    unused = torch.nn.Parameter(torch.ones(3))                                                      # 61 in all: 61 % 8 = 5
+    ps = list(net.parameters()) + [unused]
+    P.broadcast_parameters_(ps, src=0)
+    out = []
+    for overlap in (False, True):
+        fg = P.FlatGradients(ps, overlap=overlap, bucket_bytes=64) if overlap else P.FlatGradients(ps)
+        assert all((hi - lo) % world == 0 for lo, hi in fg.buckets)          # every bucket splits evenly over the ranks
+        for step in range(3):
+            fg.zero_()
+            xb = torch.randn(4, 7, generator=torch.Generator().manual_seed(100 * step + rank))
+            net(xb).pow(2).sum().backward()
+            mine = [p.grad.clone() for p in ps]
+            started = fg._next if overlap else -1
+            sent = fg.exchange_mean_()
+            out.append((overlap, step, mine, [p.grad.clone() for p in ps], sent, started))
+    lo, hi = P.shard_range(13, world, rank)            # 13 images over 8 ranks: five ranks take 2, three take 1
+    q.put(_plain((rank, out, (lo, hi), P.max_over_ranks(float(rank)), P.rank_seed(11, rank))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [8])
+def test_exchange_at_the_shipping_world_size(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_world, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([_tensors(q.get(timeout=300)) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    outs = [r[1] for r in res]
+    for k in range(len(outs[0])):                      # 2 exchange forms x 3 steps
+        overlap, step = outs[0][k][0], outs[0][k][1]
+        mean = [sum(o[k][2][i] for o in outs) / world for i in range(len(outs[0][k][2]))]
+        for o in outs:
+            assert o[k][4] == outs[0][k][4]                                   # same bytes on the wire on every rank
+            assert o[k][5] == outs[0][k][5]                                   # same buckets started from the hooks
+            for a, b, m in zip(o[k][3], outs[0][k][3], mean):
+                assert torch.equal(a, b)                                      # replicas stay bitwise identical
+                assert torch.allclose(a, m, rtol=1e-6, atol=1e-7), (overlap, step)
+            assert torch.equal(o[k][3][-1], torch.zeros(3))                   # the parameter outside the graph: zero gradient
+        if overlap and step >= 1:
+            assert outs[0][k][5] >= 1, "from the second step on the buckets must leave during backward (skip_unused)"
+    ranges = [r[2] for r in res]
+    assert ranges[0][0] == 0 and ranges[-1][1] == 13 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    assert sorted(hi - lo for lo, hi in ranges) == [1, 1, 1, 2, 2, 2, 2, 2]
+    assert all(r[3] == float(world - 1) for r in res)
+    assert len({r[4] for r in res}) == world           # distinct per-rank seeds
