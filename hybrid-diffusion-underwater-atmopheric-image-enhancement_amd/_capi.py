@@ -155,6 +155,21 @@ def build(verbose: bool = False, clean: bool = False) -> str:
     return LIB_PATH
 
 
+MUTANT_PATH = os.path.join(CSRC, "build", "libhdiff_mutant.so")
+
+
+def build_mutant(verbose: bool = False) -> str:
+    """Test infrastructure (tests/test_gpu_mutation.py): the library with ONE lowest-order piece product dropped in each
+    split-operand forward kernel (csrc/common.h, HDIFF_MUTANT).  Never loaded by the product."""
+    res = subprocess.run(["make", "-C", CSRC, "-j4", "mutant"], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0 or not os.path.isfile(MUTANT_PATH):
+        raise RuntimeError("building libhdiff_mutant.so failed")
+    return MUTANT_PATH
+
+
 def lib() -> C.CDLL:
     """Load libhdiff.so; raise loudly if it is not built (there is no fallback path)."""
     global _lib

@@ -65,7 +65,7 @@ def test_c2_unet_128_against_the_real_reference():
             y = m(x, t, torch.tensor([lab], device=DEV))
             e = maxerr(y, T_(d[f"eps_label{lab}"]))
             print(f"unet_default128 label={lab} max err {e:.3e} (ref max {np.abs(d[f'eps_label{lab}']).max():.3f})")
-            assert e < 2e-4, (lab, e)
+            assert e < 1e-4, (lab, e)          # SURVEY 8(d); measured 6.4e-5 (f32 mode) / 2.4e-5 (split mode) against the real reference
     flops = m.plan_for(1, 128, 128, torch.device(DEV)).plan.flops
     assert abs(flops / 529.6e9 - 1.0) < 0.01, flops
 
@@ -90,9 +90,9 @@ def test_c2_sampler_steps_128_against_the_real_reference():
         again = samp(x_T, labels, noise_by_step=z)                                        # hipGraph replay
     errs = [maxerr(x, T_(d["traj_preclip"][i])) for i, x in enumerate(traj)]
     print("128x128 B=2 per-step max err", ["%.2e" % e for e in errs], "pre-clip |x| max %.2f" % traj[-1].abs().max().item())
-    assert max(errs) < 1e-3
+    assert max(errs) < 1e-4                # SURVEY 8(d); measured 2.3e-5 (f32 mode) / 1.3e-5 (split mode)
     assert torch.equal(got, again)
-    assert maxerr(got, T_(d["x_0"])) < 1e-3
+    assert maxerr(got, T_(d["x_0"])) < 1e-4
     assert O.psnr(got.cpu() * 0.5 + 0.5, T_(d["x_0"]) * 0.5 + 0.5) > 60.0
 
 
@@ -452,4 +452,4 @@ def test_c5_sampler_step_512_at_batch_8():
         one = one_step(x_T[i:i + 1].contiguous(), labels[i:i + 1].contiguous(), z[i:i + 1].contiguous(), graph=False)[0]
         worst = max(worst, (one - big[0][i:i + 1]).abs().max().item())
     print(f"C5 B=8 captured step vs eight B=1 steps: max abs diff {worst:.2e}")
-    assert worst < 2e-4
+    assert worst < 1e-4

@@ -61,7 +61,8 @@ def test_c1_sampling_64x64_T50_matches_cpu_path():
             worst = max((a.cpu() - b).abs().max().item() for a, b in zip(traj, ref_traj))
             psnr, ssim = quality(out, ref)
             print(f"C1 {mode}: worst pre-clip trajectory error {worst:.2e}, PSNR {psnr:.1f} dB, SSIM {ssim:.6f}")
-            assert worst < 5e-3 and psnr >= 40.0 and ssim >= 0.99, (mode, worst, psnr, ssim)
+            # measured: 1.9e-6 / 144 dB in both modes (SURVEY 8(d) asks for >= 40 dB)
+            assert worst < 5e-5 and psnr >= 100.0 and ssim >= 0.999999, (mode, worst, psnr, ssim)
     finally:
         hdiff_amd.set_contraction_mode(before)
 

@@ -80,7 +80,7 @@ def test_unet_small_forward_golden():
             y = m(T(d[f"s{S}/x"]).to(DEV), T(d[f"s{S}/t"]).to(DEV), T(d[f"s{S}/labels"]).to(DEV))
             e = maxerr(y, T(d[f"s{S}/eps"]))
             print(f"unet_small S={S} max err {e:.3e}")
-            assert e < 2e-4, (S, e)
+            assert e < 1e-4, (S, e)            # eps <= 1e-4; measured 3.0e-5
         # weights changed in place -> packed weights refresh -> output follows
         y0 = m(T(d["s16/x"]).to(DEV), T(d["s16/t"]).to(DEV), T(d["s16/labels"]).to(DEV))
         m.tail[2].bias.add_(1.0)
@@ -113,7 +113,7 @@ def test_unet_default64_golden_seeded_weights():
             y = m(T(d["x"]).to(DEV), T(d["t"]).to(DEV), torch.tensor([lab], device=DEV))
             e = maxerr(y, T(d[f"eps_label{lab}"]))
             print(f"unet_default64 label={lab} max err {e:.3e}")
-            assert e < 2e-4, (lab, e)
+            assert e < 7e-5, (lab, e)          # measured 7.2e-6: ten times that (SURVEY 8(d) allows 1e-4)
     # the plan's own FLOP count (convolutions + attention) against SURVEY.md section 8a: 74.0 GFLOP per sample-forward at 64x64
     flops = m.plan_for(1, 64, 64, torch.device(DEV)).plan.flops
     assert abs(flops / 74.0e9 - 1.0) < 0.01, flops
@@ -136,9 +136,9 @@ def test_sampler_small_teacher_forced_and_graph():
         ref = d[f"{tag}/traj_preclip"]
         errs = [maxerr(x, T(ref[i])) for i, x in enumerate(traj)]
         print(tag, "per-step max err", ["%.2e" % e for e in errs])
-        assert max(errs) < 1e-3
+        assert max(errs) < 1e-4            # teacher-forced step <= 1e-4; measured 1.2e-5 over all eight
         assert torch.equal(y_eager, y_graph), "graph replay must reproduce the eager launches bit for bit"
-        assert maxerr(y_graph, T(d[f"{tag}/x_0"])) < 1e-3
+        assert maxerr(y_graph, T(d[f"{tag}/x_0"])) < 1e-4
         assert O.psnr(y_graph.cpu() * 0.5 + 0.5, T(d[f"{tag}/x_0"]) * 0.5 + 0.5) > 60.0
         assert float(y_graph.min()) >= -1 and float(y_graph.max()) <= 1
 
@@ -204,7 +204,7 @@ def test_unet_vs_oracle_larger_shape():
         y = m.to(DEV)(x.to(DEV), t.to(DEV), lab.to(DEV))
     e = maxerr(y, ref)
     print(f"unet 64x64 two-level max err {e:.3e}")
-    assert e < 2e-4
+    assert e < 1e-4
 
 
 @pytest.mark.parametrize("B,H,W", [(3, 8, 8), (1, 16, 24), (5, 8, 40)])
@@ -265,7 +265,7 @@ def test_unet_wide_levels_golden_forward_and_training():
         y = m(T(d["x"]).to(DEV), T(d["t"]).to(DEV), T(d["labels"]).to(DEV))
     e = maxerr(y, T(d["eps"]))
     print(f"unet_wide max err {e:.3e}")
-    assert e < 2e-4
+    assert e < 1e-4
     m.train()
     tr = DC.GaussianDiffusionTrainer(m, 1e-4, 0.02, c["T"]).to(DEV)
     x_0 = T(d["x_0"]).to(DEV)
