@@ -312,6 +312,77 @@ def test_flash_attention_split_bf16_is_fp32_class(d, L, B, scale, workspace, bf1
     assert worst(o_x3) <= 2.0 * worst(o_f32) + 1e-12, (worst(o_x3), worst(o_f32))
 
 
+def _h2_case(name, d, L, g):
+    """Inputs that stress what the fp16-pair P.V kernel (attention_h2.hip) adds to the bf16-triple one: a softmax reference
+    that has to move, and fp16's range."""
+    heads = 8
+    qkv = torch.randn(1, 3 * heads * d, L, generator=g)
+    Cc = heads * d
+    if name == "ramp":            # the row maximum keeps rising along the keys
+        qkv[:, Cc:2 * Cc] *= torch.linspace(0.3, 5.0, L)
+    elif name == "peaked":        # scores with a standard deviation of 13 in the exp2 domain
+        qkv *= 3.0
+    elif name == "late-spikes":   # a few keys far above everything before them (jumps of ~2^100 in P), in the middle and at the end
+        qkv[:, Cc:2 * Cc, L // 2 + 5] *= 25.0
+        qkv[:, Cc:2 * Cc, L - 3] *= 40.0
+    elif name == "wide-v":        # V channels spanning 2^30 between and 2^12 within rows
+        qkv[:, 2 * Cc:] *= torch.exp(torch.randn(1, Cc, 1, generator=g) * 6) * torch.exp(torch.randn(1, Cc, L, generator=g) * 2)
+    elif name == "tiny-v":        # a head whose V is denormal-small next to normal ones
+        qkv[:, 2 * Cc:2 * Cc + d] *= 1e-30
+    return qkv
+
+
+@pytest.mark.parametrize("name", ["ramp", "peaked", "late-spikes", "wide-v", "tiny-v"])
+def test_flash_attention_fp16_pairs_moving_reference_and_ranges(name, bf16x3_mode):
+    """attention_h2.hip (d_head 16 with a workspace): P as two fp16 pieces needs a reference that MOVES (fp16 ends at 65504)
+    and V scaled per channel row.  Error against float64 in the class of the fp32-MFMA kernel's on the same inputs, and --
+    in a process that skips the check pass -- not a single NaN: the kernel handled every row itself instead of poisoning
+    it for the fp32 kernel behind it."""
+    lib = bf16x3_mode
+    d, L, heads = 16, 4096, 8
+    g = torch.Generator().manual_seed({"ramp": 1, "peaked": 2, "late-spikes": 3, "wide-v": 4, "tiny-v": 5}[name])
+    qkv = _h2_case(name, d, L, g)
+    ref = attention_core_ref(qkv, heads).double()
+    o_h2, _ = _flash(lib, qkv, heads, workspace=True)
+    _capi.check(lib.hdiff_set_contraction_mode(0))
+    o_f32, _ = _flash(lib, qkv, heads)
+    _capi.check(lib.hdiff_set_contraction_mode(1))
+    assert torch.isfinite(o_h2).all()
+    scale = ref.abs().amax(dim=2, keepdim=True).clamp_min(1e-300)          # per channel row: rows differ by 2^30 in "wide-v"
+    rms = lambda t: ((t.double().cpu() - ref) / scale).pow(2).mean().sqrt().item()
+    worst = lambda t: ((t.double().cpu() - ref) / scale).abs().max().item()
+    print(f"h2 {name}: rms {rms(o_h2):.3e} (fp32-MFMA kernel {rms(o_f32):.3e}), worst {worst(o_h2):.3e} ({worst(o_f32):.3e})")
+    assert rms(o_h2) <= 1.25 * rms(o_f32) + 1e-12, (rms(o_h2), rms(o_f32))
+    assert worst(o_h2) <= 2.0 * worst(o_f32) + 1e-12, (worst(o_h2), worst(o_f32))
+
+
+def test_flash_attention_fp16_pairs_keeps_every_row_in_the_kernel():
+    """The same inputs with the check pass switched off (HDIFF_NO_CHECK_PASS, read once per process): no NaN anywhere, i.e.
+    the moving reference kept every P inside fp16 -- none of these rows was handed to the fp32 kernel."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, hdiff_amd
+from hdiff_amd import _capi
+import test_gpu_ops as T
+lib = hdiff_amd.lib(); hdiff_amd.set_contraction_mode("bf16x3")
+for i, name in enumerate(["ramp", "peaked", "late-spikes", "wide-v"]):
+    qkv = T._h2_case(name, 16, 4096, torch.Generator().manual_seed(i + 1))
+    o, lse = T._flash(lib, qkv, 8, want_lse=True, workspace=True)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all(), name
+    ref = T.attention_core_ref(qkv, 8)
+    assert ((o.cpu() - ref).abs().amax(dim=2) <= 3e-5 * ref.abs().amax(dim=2) + 1e-30).all(), name
+print("H2_ROWS_OK")
+''' % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, HDIFF_NO_CHECK_PASS="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0 and "H2_ROWS_OK" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
 @pytest.mark.parametrize("workspace", [False, True], ids=["split-in-loop", "pre-split"])
 def test_flash_attention_split_bf16_overflow_falls_back(workspace, bf16x3_mode):
     """Same fixed-reference protocol as the fp32 fast kernel: spiked keys / queries overflow exp2 on purpose; the poisoned

@@ -13,8 +13,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define MFMA_BF16(acc, a, b, c) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc) : "v"(a), "v"(b), "v"(c))
 #define MFMA_F16(acc, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 
-template <int DEP, int PAT>
+// QKH = 1: the candidate with Q K^T on fp16 pairs of range-scaled operands (four products = two MFMAs per 16x16 tile, one
+// K operand set) and one v_mul_f32 per score that takes the scale out again: 14 MFMA + 72 vector instructions per stage
+template <int DEP, int PAT, int QKH>
 __global__ __launch_bounds__(256, 2) void stage_kernel(float* out, int iters, float seed, float one) {
+  constexpr int NMF = QKH ? 14 : 18, NVS = QKH ? 72 : 56, VPK = QKH ? 18 : 14;
   u32x4 kop[4][3], qcur[3], vop[2][2];
   f32x4 S[2][4], O[4], negm;
   u32x4 pop[2][2][2];
@@ -39,7 +42,12 @@ __global__ __launch_bounds__(256, 2) void stage_kernel(float* out, int iters, fl
       float pe[4][4], ad[4][2];
       unsigned u[4][2], r2[4][2];
       auto vstep = [&](int n) {
-        const int kt = n / 14, r = n - kt * 14;
+        const int kt = n / VPK;
+        int r = n - kt * VPK;
+        if (QKH) {
+          if (r < 4) { asm volatile("v_mul_f32 %0, %1, %0" : "+v"(S[par][kt][r]) : "s"(one)); return; }
+          r -= 4;
+        }
         if (r < 4) {
           if (DEP & 1) asm volatile("v_exp_f32 %0, %1" : "=v"(pe[kt][r]) : "v"(S[par][kt][r]));
           else asm volatile("v_exp_f32 %0, %1" : "=v"(pe[kt][r]) : "v"(priv[kt * 4 + r]));
@@ -51,6 +59,19 @@ __global__ __launch_bounds__(256, 2) void stage_kernel(float* out, int iters, fl
         else asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum1) : "v"(ad[kt][1]));
       };
       auto mstep = [&](int i) {
+        if (QKH) {
+          const int np = (i + 1) * 6 / 14, pp = i * 6 / 14;
+          if (np != pp) {
+            const int n = pp, c = n / 3, term = n - c * 3;
+            if (DEP & 2) MFMA_F16(O[(st + 3) & 3], vop[term == 0 ? 1 : 0][c], pop[par ^ 1][term == 1 ? 1 : 0][c]);
+            else MFMA_F16(O[(st + 3) & 3], vop[term == 0 ? 1 : 0][c], vop[term == 1 ? 1 : 0][c]);
+          } else {
+            const int n = i - pp, j = n >> 2, kt = n & 3;
+            if (j == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=v"(S[par ^ 1][kt]) : "v"(kop[kt][0]), "v"(qcur[j]), "v"(negm));
+            else MFMA_F16(S[par ^ 1][kt], kop[kt][0], qcur[j]);
+          }
+          return;
+        }
         if (i % 3 == 2) {
           const int n = i / 3, c = n / 3, term = n - c * 3;
           if (DEP & 2) MFMA_F16(O[(st + 3) & 3], vop[term == 0 ? 1 : 0][c], pop[par ^ 1][term == 1 ? 1 : 0][c]);
@@ -63,16 +84,16 @@ __global__ __launch_bounds__(256, 2) void stage_kernel(float* out, int iters, fl
       };
       if (PAT == 0) {
 #pragma unroll
-        for (int i = 0; i < 18; ++i) {
+        for (int i = 0; i < NMF; ++i) {
           mstep(i);
 #pragma unroll
-          for (int n = 56 * i / 18; n < 56 * (i + 1) / 18; ++n) vstep(n);
+          for (int n = NVS * i / NMF; n < NVS * (i + 1) / NMF; ++n) vstep(n);
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 18; ++i) mstep(i);
+        for (int i = 0; i < NMF; ++i) mstep(i);
 #pragma unroll
-        for (int n = 0; n < 56; ++n) vstep(n);
+        for (int n = 0; n < NVS; ++n) vstep(n);
       }
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
@@ -90,15 +111,15 @@ __global__ __launch_bounds__(256, 2) void stage_kernel(float* out, int iters, fl
   out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)pop[0][0][0][0] + (float)pop[1][1][1][3];
 }
 
-template <int DEP, int PAT>
+template <int DEP, int PAT, int QKH = 0>
 void run(const char* name, int w, float* out) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int iters = 2000;
-  stage_kernel<DEP, PAT><<<256 * w, 256>>>(out, 50, 0.3f, 1.0f);
+  stage_kernel<DEP, PAT, QKH><<<256 * w, 256>>>(out, 50, 0.3f, 1.0f);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0);
-  stage_kernel<DEP, PAT><<<256 * w, 256>>>(out, iters, 0.3f, 1.0f);
+  stage_kernel<DEP, PAT, QKH><<<256 * w, 256>>>(out, iters, 0.3f, 1.0f);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms;
@@ -117,6 +138,8 @@ int main() {
     run<3, 0>("both (the kernel), spread", w, out);
     run<0, 1>("no dependencies, clumped", w, out);
     run<3, 1>("both, clumped", w, out);
+    run<0, 0, 1>("fp16-pair QK candidate: no dependencies, spread", w, out);
+    run<3, 0, 1>("fp16-pair QK candidate: both, spread", w, out);
   }
   printf("(kernel: 149.8 ms per launch at L = 65536, B = 16 = 285.7 ns per stage and SIMD)\n");
   return 0;
