@@ -45,6 +45,7 @@ class ConvDesc(C.Structure):
         ("out_sy", C.c_int), ("out_oy", C.c_int), ("out_sx", C.c_int), ("out_ox", C.c_int),
         ("ntaps", C.c_int), ("tap_dy", C.c_int * MAX_TAPS), ("tap_dx", C.c_int * MAX_TAPS),
         ("splitk_ws", C.c_void_p), ("splitk_floats", C.c_int64), ("wp_x3", C.c_void_p),
+        ("wp_h2", C.c_void_p), ("act_scale", C.c_void_p),
     ]
 
 
@@ -67,6 +68,9 @@ _PROTOS = {
     "hdiff_pack_conv_weight_x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hdiff_pack_conv_weight_x3_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p]),
+    "hdiff_pack_conv_weight_h2_words": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "hdiff_pack_conv_weight_h2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hdiff_gn_act_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "hdiff_set_contraction_mode": (C.c_int, [C.c_int]),
     "hdiff_get_contraction_mode": (C.c_int, []),
     "hdiff_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -45,9 +45,11 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 # launch helpers (immediate execution)
 # ----------------------------------------------------------------------------------------------------------------------
 def _run_conv(x0, x1, sources, taps: E.TapSet, cout: int, cin: int, bias, out, *, B, H, W, VH, VW, in_stride=1,
-              out_map=(1, 0, 1, 0), gn=None, addvec=None, residual=None, x3=None) -> None:
+              out_map=(1, 0, 1, 0), gn=None, addvec=None, residual=None, x3=None, act_range=None) -> None:
     """x3 = (forward weight [3x3], transposed?): also pack the split-bf16 copy, so that a plain 3x3 / stride-1 launch (the
-    forward conv, or its input-gradient conv on the transposed, mirrored weight) runs conv3x3_x3.hip in the bf16x3 mode."""
+    forward conv, or its input-gradient conv on the transposed, mirrored weight) runs conv3x3_x3.hip in the bf16x3 mode.
+    act_range = (gamma, beta, group_elems, gain) of the GroupNorm + Swish the input went through (Plan.conv): the forward conv
+    then takes that kernel's fp16-pair form."""
     plan = E.Plan(x0.device)
     pk = E.PackedConv(x0.device, cout, cin, taps)
     for (w, mode, ky, kx, acc) in sources:
@@ -56,7 +58,7 @@ def _run_conv(x0, x1, sources, taps: E.TapSet, cout: int, cin: int, bias, out, *
         pk.enable_x3(x3[0], transposed=x3[1])
     plan.packs.append(pk)
     plan.conv(x0, x1, pk, bias, out, B=B, H=H, W=W, VH=VH, VW=VW, in_stride=in_stride, out_map=out_map, gn=gn,
-              addvec=addvec, residual=residual)
+              addvec=addvec, residual=residual, act_range=act_range)
     plan.pack_weights()
     plan.run()
 
@@ -139,12 +141,15 @@ class _FusedConv(Function):
         cout, cin = int(weight.shape[0]), int(weight.shape[1])
         assert cin == C0 + C1
         pad = k // 2
-        gn = mean = rstd = mask = None
+        gn = mean = rstd = mask = act_range = None
         conv_in0, conv_in1, conv_gn = x0, x1, None
         if gn_w is not None:
             scale, shift, mean, rstd = _gn_stats(x0, x1, gn_w, gn_b, B, H * W)
             gn = (scale, shift)
             conv_gn = gn
+            # the conv's input is swish(GroupNorm(x)) (times mask / keep behind the dropout): its range follows from the
+            # GroupNorm weights, which is what the fp16-pair 3x3 kernel stages its activations by
+            act_range = (gn_w.detach(), gn_b.detach(), (cin // GN_GROUPS) * H * W, 1.0 / (1.0 - drop_p) if drop_p > 0.0 else 1.0)
             if drop_p > 0.0:
                 # nn.Dropout sits between Swish and the conv (ModelCondition.py:185): materialise a = swish(gn(x)) * mask
                 assert x1 is None
@@ -160,7 +165,8 @@ class _FusedConv(Function):
         taps = E.conv_taps(k, pad)
         out = torch.empty(B, cout, H, W, device=dev)
         _run_conv(conv_in0, conv_in1, [(weight, 0, taps.ky, taps.kx, 0)], taps, cout, cin, bias, out, B=B, H=H, W=W, VH=H,
-                  VW=W, gn=conv_gn, addvec=addvec, residual=residual, x3=(weight, False) if k == 3 else None)
+                  VW=W, gn=conv_gn, addvec=addvec, residual=residual, x3=(weight, False) if k == 3 else None,
+                  act_range=act_range if k == 3 else None)
         ctx.k, ctx.has_x1, ctx.has_gn, ctx.dropped = k, x1 is not None, gn_w is not None, mask is not None
         ctx.has_bias, ctx.has_vec, ctx.has_res = bias is not None, addvec is not None, residual is not None
         saved = [x0, x1, weight, gn_w, gn_b, mean, rstd, gn[0] if gn else None, gn[1] if gn else None, mask,

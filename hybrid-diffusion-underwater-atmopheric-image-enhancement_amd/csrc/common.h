@@ -93,6 +93,10 @@ struct ConvX3K {
   int ntaps;                       // 9, 6 or 4
   int tap_off[9];                  // LDS word offset of the tap inside the staged patch: ((dy + 1) * 34 + (dx + 1)) * 4
   int OH, OW, out_sy, out_oy, out_sx, out_ox;     // output pixel (vy * out_sy + out_oy, vx * out_sx + out_ox) of an OH x OW plane
+  // fp16-pair form (plain 3x3 behind GroupNorm + Swish): wp3 then holds [Cin/16][9][2][CoutPad][8] words of w 2^t
+  const float* act_scale;          // device {2^s, 2^-s} of the staged activations (hdiff_gn_act_scale), NULL = bf16 triples
+  const float* w_scale;            // the pack's tail {bits of max |w|, 2^-t, 2^t, 0} (hdiff_pack_conv_weight_h2)
+  float one;                       // 1.0f, opaque to the compiler
 };
 void launch_conv3x3_x3(const ConvX3K& k, int B, hipStream_t stream);
 

@@ -15,6 +15,23 @@
 //   * the weights are not staged: hdiff_pack_conv_weight_x3 lays them out as [chunk][tap][piece][channel][16 ci], so a lane's
 //     A operand is one 16-byte global load (L1/L2 resident: every workgroup of the launch reads the same 55 KB per chunk);
 //   * per tap 6 piece pairs x (2 x 2) tiles = 24 MFMAs; the next tap's weight loads are issued before them.
+//
+// PAIR (round 4): the same kernel with both operands as fp16 PAIRS instead of bf16 triples (v_mfma_f32_32x32x16_f16), for
+// convolutions with the GroupNorm + Swish prologue.  fp16 carries 11 significand bits, a pair x' = h0 + h1 holds 22-23 of
+// fp32's 24 (attention_h2.hip has the split: v_cvt_pk_f16_f32 + v_fma_mixlo / mixhi_f16, 1.5 instructions per value against
+// 5.5), and THREE products (w1 x0, w0 x1, w0 x0; dropped: w1 x1 <= 2^-22) replace six.  What fp16 lacks is range, and here the
+// range is known before a single activation is read: the staged value is swish(gamma xhat + beta) with |xhat| <= sqrt(n - 1)
+// for a group of n elements, so |value| <= sqrt(n - 1) max |gamma| + max |beta| =: A (hdiff_gn_act_scale evaluates it from the
+// GroupNorm weights alone).  Activations are staged times 2^s with A 2^s < 2^15, weights are packed times 2^t with
+// max |w| 2^t in [2^14, 2^15) (hdiff_pack_conv_weight_h2); the accumulator leaves through one multiplication by 2^-(s + t).
+// Error of an operand: 2^-23 relative, or 2^-25 absolute in the scaled domain for values below 2^-3 there -- i.e. below
+// 2^-18 of A resp. max |w|: fp32-class against the sum it enters (tests/test_gpu_ops.py holds the kernel to the bf16-triple
+// kernel's gate: error against float64 within 1.5x of the fp32-MFMA kernel's).  The chain has 3 roundings per 16 input
+// channels and tap instead of 6, and measures a SMALLER error than the bf16 triples (tools/h2_sim_conv.py).  A caller whose
+// gn_scale / gn_shift are not GroupNorm statistics of x can break the bound: the fp16 conversion then yields inf and the
+// output NaN -- loud, never silently wrong.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -32,6 +49,8 @@ constexpr int PSTRIDE = PIECE_WORDS + 8;              // plane stride: each plan
 constexpr int DUMP_WORD = PIECE_WORDS;                // ... where the unused staging slot of a thread stores (branch-free staging)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float swish_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -54,6 +73,21 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& h0, unsigned&
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// (a, b) -> two packed fp16 pairs with a = h0.lo + h1.lo up to 2^-23 |a| (or 2^-25 absolute), b likewise in the high halves
+// (attention_h2.hip).  `one` is 1.0f in a register the compiler cannot see through: fma(a, 1, -h) must stay an fma
+// (v_fma_mixlo / mixhi_f16: the residual is exact in fp32 and rounded once).
+__device__ __forceinline__ void split2(float a, float b, float one, unsigned& h0, unsigned& h1) {
+  const f16x2 p = {(_Float16)a, (_Float16)b};                 // v_cvt_pk_f16_f32: round to nearest even
+  unsigned u = __builtin_bit_cast(unsigned, p);
+  asm("" : "+v"(u));
+  const f16x2 q = __builtin_bit_cast(f16x2, u);
+  const f16x2 r = {(_Float16)__builtin_fmaf(a, one, -(float)q[0]), (_Float16)__builtin_fmaf(b, one, -(float)q[1])};
+  h0 = u;
+  h1 = __builtin_bit_cast(unsigned, r);
+}
 
 // split-product terms kept (piece of W, piece of X): all i + j <= 2, small ones first
 __device__ constexpr int TERM_W[6] = {2, 1, 0, 1, 0, 0};
@@ -61,9 +95,11 @@ __device__ constexpr int TERM_X[6] = {0, 1, 2, 0, 1, 0};
 
 // NT: taps of the launch (9 = the 3x3 conv, 6 / 4 = transposed-conv phases with fewer taps); OUTMAP: the output pixel of
 // (vy, vx) is (vy * out_sy + out_oy, vx * out_sx + out_ox) of an OH x OW plane (transposed-conv phases) instead of (vy, vx).
-template <int NT, bool OUTMAP>
-__global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
-  __shared__ __attribute__((aligned(16))) unsigned sXbuf[2][3 * PSTRIDE];     // double-buffered: chunk c + 1 is staged beside chunk c's MFMAs
+// PAIR: fp16 pairs and three products instead of bf16 triples and six (header).
+template <int NT, bool OUTMAP, bool PAIR, int OCC = 1>
+__global__ __launch_bounds__(THREADS, OCC) void conv3x3_x3_kernel(const ConvX3K p) {
+  constexpr int NP = PAIR ? 2 : 3;         // pieces per operand
+  __shared__ __attribute__((aligned(16))) unsigned sXbuf[2][NP * PSTRIDE];     // double-buffered: chunk c + 1 is staged beside chunk c's MFMAs
   extern __shared__ __attribute__((aligned(16))) float sG[];     // [2][Cin]: GroupNorm scale | shift of this sample
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,6 +110,8 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   const int vy0 = tile_y * 8, vx0 = tile_x * 32;
   const bool has_gn = p.gn_scale != nullptr;
   const size_t HW = (size_t)p.H * p.W;
+  const float xs = PAIR ? p.act_scale[0] : 1.0f;       // 2^s of the staged activations
+  const float one = p.one;
 
   // LDS layout of a piece: two half-planes [h][pixel][4 words]; word w of half h holds the bf16 pieces of input channels
   // 8h + 2w, 8h + 2w + 1.  A lane's B operand (8 channels of one pixel) is ONE 16-byte read and consecutive lanes read
@@ -140,13 +178,22 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
         v[k] = inside ? gk : 0.f;
       }
     }
-    unsigned a0, a1, a2, c0w, c1w, c2w;
-    split3(v[0], v[1], a0, a1, a2);
-    split3(v[2], v[3], c0w, c1w, c2w);
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    *reinterpret_cast<u32x2*>(&sX[s_lds[i]]) = u32x2{a0, c0w};
-    *reinterpret_cast<u32x2*>(&sX[PSTRIDE + s_lds[i]]) = u32x2{a1, c1w};
-    *reinterpret_cast<u32x2*>(&sX[2 * PSTRIDE + s_lds[i]]) = u32x2{a2, c2w};
+    if constexpr (PAIR) {
+      unsigned a0, a1, c0w, c1w;
+      split2(v[0] * xs, v[1] * xs, one, a0, a1);
+      split2(v[2] * xs, v[3] * xs, one, c0w, c1w);
+      if (HDIFF_MUTANT & 1) { a1 &= 0xffe0ffe0u; c1w &= 0xffe0ffe0u; }      // (mutation test: 2^-16 of every activation dropped)
+      *reinterpret_cast<u32x2*>(&sX[s_lds[i]]) = u32x2{a0, c0w};
+      *reinterpret_cast<u32x2*>(&sX[PSTRIDE + s_lds[i]]) = u32x2{a1, c1w};
+    } else {
+      unsigned a0, a1, a2, c0w, c1w, c2w;
+      split3(v[0], v[1], a0, a1, a2);
+      split3(v[2], v[3], c0w, c1w, c2w);
+      *reinterpret_cast<u32x2*>(&sX[s_lds[i]]) = u32x2{a0, c0w};
+      *reinterpret_cast<u32x2*>(&sX[PSTRIDE + s_lds[i]]) = u32x2{a1, c1w};
+      *reinterpret_cast<u32x2*>(&sX[2 * PSTRIDE + s_lds[i]]) = u32x2{a2, c2w};
+    }
   };
   auto store_staged = [&](auto gn_tag, int c0, unsigned* sX) {
 #pragma unroll
@@ -160,25 +207,31 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   for (int nt = 0; nt < 4; ++nt) boff[nt] = h * HALF_WORDS + ((wn * 4 + nt) * PW + l31) * 4;
   const unsigned* wlane = p.wp3 + ((size_t)(co0 + wm * 32 + l31) * 8 + h * 4);
   const size_t w_piece = (size_t)p.CoutPad * 8;            // words between pieces
-  const size_t w_tap = 3 * w_piece, w_chunk = NT * w_tap;
+  const size_t w_tap = NP * w_piece, w_chunk = NT * w_tap;
 
-  auto load_w = [&](u32x4 (&wa)[3], int chunk, int tap) {
+  auto load_w = [&](u32x4 (&wa)[NP], int chunk, int tap) {
     const unsigned* wb = wlane + (size_t)chunk * w_chunk + (size_t)tap * w_tap;
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) wa[pc] = *reinterpret_cast<const u32x4*>(wb + pc * w_piece);
+    for (int pc = 0; pc < NP; ++pc) wa[pc] = *reinterpret_cast<const u32x4*>(wb + pc * w_piece);
   };
-  // One unit = (tap, pixel row nt): 6 MFMAs on acc[nt].  The B operands of unit u + 1 are read from LDS at the start of unit
+  // One unit = (tap, pixel row nt): 6 MFMAs on acc[nt] (PAIR: 3).  The B operands of unit u + 1 are read from LDS at the start of unit
   // u and the weights of tap + 2 are requested at the start of tap (two taps = 1 500 MFMA cycles ahead: an L2 hit under load
   // takes about one tap), so that no unit starts by waiting for its own operands.
-  auto load_x = [&](u32x4 (&xp)[3], const unsigned* sX, int tap, int nt) {
+  auto load_x = [&](u32x4 (&xp)[NP], const unsigned* sX, int tap, int nt) {
     const int toff = p.tap_off[tap];                    // ((dy + 1) * PW + (dx + 1)) * 4, wave-uniform
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) xp[pc] = *reinterpret_cast<const u32x4*>(&sX[pc * PSTRIDE + boff[nt] + toff]);
+    for (int pc = 0; pc < NP; ++pc) xp[pc] = *reinterpret_cast<const u32x4*>(&sX[pc * PSTRIDE + boff[nt] + toff]);
   };
-  auto mma_unit = [&](const u32x4 (&wa)[3], const u32x4 (&xp)[3], int nt) {
+  auto mma_unit = [&](const u32x4 (&wa)[NP], const u32x4 (&xp)[NP], int nt) {
+    if constexpr (PAIR) {                  // small products first
+      acc[nt] = mfma_f16(wa[1], xp[0], acc[nt]);
+      acc[nt] = mfma_f16(wa[0], xp[1], acc[nt]);
+      acc[nt] = mfma_f16(wa[0], xp[0], acc[nt]);
+    } else {
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
-      if (!((HDIFF_MUTANT & 1) && TERM_W[t] == 0 && TERM_X[t] == 2)) acc[nt] = mfma_bf16(wa[TERM_W[t]], xp[TERM_X[t]], acc[nt]);
+      for (int t = 0; t < 6; ++t)
+        if (!((HDIFF_MUTANT & 1) && TERM_W[t] == 0 && TERM_X[t] == 2)) acc[nt] = mfma_bf16(wa[TERM_W[t]], xp[TERM_X[t]], acc[nt]);
+    }
   };
 
   // Chunk loop, ONE barrier per chunk: while the matrix core works through chunk c (LDS buffer c & 1), the vector pipe turns
@@ -188,7 +241,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
     constexpr bool more = decltype(more_tag)::value;      // compile time: the staging must not sit in a block of its own
     const unsigned* sX = sXbuf[c & 1];
     unsigned* sNext = sXbuf[(c + 1) & 1];
-    u32x4 w[3][3], xp[2][3];
+    u32x4 w[3][NP], xp[2][NP];
     load_w(w[0], c, 0);
     load_w(w[1], c, 1);
     load_x(xp[0], sX, 0, 0);
@@ -231,6 +284,13 @@ __global__ __launch_bounds__(THREADS) void conv3x3_x3_kernel(const ConvX3K p) {
   // bias / vector values of the lane's channels are fetched together, then per pixel row all 16 residual loads are in
   // flight before the first add -- with per-element tests every output waited for its own three loads in turn (64 dependent
   // round trips per lane: a quarter of the kernel's time at 128 channels).
+  if constexpr (PAIR) {                    // out of the scaled domain: 2^-(s + t), exact
+    const float os = p.act_scale[1] * p.w_scale[1];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] *= os;
+  }
   const size_t OHW = OUTMAP ? (size_t)p.OH * p.OW : HW;
   const int osy = OUTMAP ? p.out_sy : 1, ooy = OUTMAP ? p.out_oy : 0, osx = OUTMAP ? p.out_sx : 1, oox = OUTMAP ? p.out_ox : 0;
   const int OW = OUTMAP ? p.OW : p.W;
@@ -321,6 +381,69 @@ __global__ void pack_conv_weight_x3_kernel(const float* __restrict__ w, unsigned
   }
 }
 
+// ---- fp16-pair weights: [Cin/16][tap][2 pieces][CoutPad][8 words] of w 2^t, then a tail of 4 words:
+//      {bits of max |w| (scratch of the pack), 2^-t, 2^t, 0}.  Two launches: the maximum, then the split.
+__global__ void conv_weight_absmax_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ tail) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(tail, __builtin_bit_cast(unsigned, m));      // non-negative floats order like unsigned integers
+}
+__global__ void pack_conv_weight_h2_kernel(const float* __restrict__ w, unsigned* __restrict__ wp2, const PackX3K q, float one) {
+  const size_t n = (size_t)(q.Cin / 16) * q.ntaps * q.CoutPad * 8;
+  unsigned* tail = wp2 + 2 * n;
+  // 2^t with max |w| 2^t in [2^14, 2^15); an all-zero / denormal / non-finite tensor gets a fixed scale (inf and NaN stay what they are)
+  int e = (int)((tail[0] >> 23) & 0xffu) - 127;
+  e = e < -60 ? -60 : (e > 60 ? 60 : e);
+  const float sc = __builtin_bit_cast(float, (unsigned)(14 - e + 127) << 23);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % 8);
+    size_t r = i / 8;
+    const int co = (int)(r % q.CoutPad);
+    r /= q.CoutPad;
+    const int tap = (int)(r % q.ntaps);
+    const int chunk = (int)(r / q.ntaps);
+    float a = 0.f, c = 0.f;
+    if (co < q.Cout) {
+      const int ci = chunk * 16 + 2 * j;
+      const size_t k = (size_t)q.ky[tap] * q.KW + q.kx[tap], kk = (size_t)q.KH * q.KW;
+      a = w[((size_t)co * q.Cin + ci) * kk + k];
+      c = w[((size_t)co * q.Cin + ci + 1) * kk + k];
+    }
+    unsigned h0, h1;
+    split2(a * sc, c * sc, one, h0, h1);
+    const size_t base = ((size_t)(chunk * q.ntaps + tap) * 2) * q.CoutPad * 8 + (size_t)co * 8 + j;
+    wp2[base] = h0;
+    wp2[base + (size_t)q.CoutPad * 8] = h1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    reinterpret_cast<float*>(tail)[1] = __builtin_bit_cast(float, (unsigned)(e - 14 + 127) << 23);
+    reinterpret_cast<float*>(tail)[2] = sc;
+    tail[3] = 0u;
+  }
+}
+
+// out[0] = 2^s, out[1] = 2^-s with (sqrt(n - 1) max |gamma| + max |beta|) 2^s in [2^13, 2^14): the bound of a GroupNorm + Swish
+// output (header) with a factor of two to spare.  One workgroup.
+__global__ void gn_act_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int C, float sqrt_n1,
+                                    float gain, float* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) m = fmaxf(m, fmaf(sqrt_n1, fabsf(gamma[i]), fabsf(beta[i])));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * gain;
+    int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);           // NaN / inf weights: a fixed scale, the activations are NaN anyway
+    out[0] = __builtin_bit_cast(float, (unsigned)(13 - e + 127) << 23);
+    out[1] = __builtin_bit_cast(float, (unsigned)(e - 13 + 127) << 23);
+  }
+}
+
 }  // namespace
 
 namespace hdiff {
@@ -330,10 +453,16 @@ void launch_conv3x3_x3(const ConvX3K& k, int B, hipStream_t stream) {
   dim3 grid(k.tiles_x * tiles_y, cdiv(k.Cout, 64), B);
   const size_t dyn = (size_t)2 * k.Cin * sizeof(float);
   const bool outmap = !(k.out_sy == 1 && k.out_oy == 0 && k.out_sx == 1 && k.out_ox == 0 && k.OH == k.H && k.OW == k.W);
-  if (k.ntaps == 9 && !outmap) hipLaunchKernelGGL((conv3x3_x3_kernel<9, false>), grid, dim3(THREADS), dyn, stream, k);
-  else if (k.ntaps == 9) hipLaunchKernelGGL((conv3x3_x3_kernel<9, true>), grid, dim3(THREADS), dyn, stream, k);
-  else if (k.ntaps == 6) hipLaunchKernelGGL((conv3x3_x3_kernel<6, true>), grid, dim3(THREADS), dyn, stream, k);
-  else hipLaunchKernelGGL((conv3x3_x3_kernel<4, true>), grid, dim3(THREADS), dyn, stream, k);
+  if (k.act_scale != nullptr) {            // fp16 pairs: the plain 3x3 conv behind GroupNorm + Swish (the dispatcher checked the shape)
+    static const char* e = getenv("HDIFF_CONV_OCC");      // dev knob: 3 = the build held to 168 registers (three workgroups per CU)
+    if (e && atoi(e) == 3) hipLaunchKernelGGL((conv3x3_x3_kernel<9, false, true, 3>), grid, dim3(THREADS), dyn, stream, k);
+    else hipLaunchKernelGGL((conv3x3_x3_kernel<9, false, true>), grid, dim3(THREADS), dyn, stream, k);
+    return;
+  }
+  if (k.ntaps == 9 && !outmap) hipLaunchKernelGGL((conv3x3_x3_kernel<9, false, false>), grid, dim3(THREADS), dyn, stream, k);
+  else if (k.ntaps == 9) hipLaunchKernelGGL((conv3x3_x3_kernel<9, true, false>), grid, dim3(THREADS), dyn, stream, k);
+  else if (k.ntaps == 6) hipLaunchKernelGGL((conv3x3_x3_kernel<6, true, false>), grid, dim3(THREADS), dyn, stream, k);
+  else hipLaunchKernelGGL((conv3x3_x3_kernel<4, true, false>), grid, dim3(THREADS), dyn, stream, k);
 }
 
 }  // namespace hdiff
@@ -362,6 +491,48 @@ extern "C" int hdiff_pack_conv_weight_x3(const float* w, void* wp3, int Cout, in
     kx[t] = transposed ? 2 - t % 3 : t % 3;
   }
   return pack_x3(w, wp3, transposed ? 1 : 0, Cout, Cin, 3, 3, 9, ky, kx, CoutPad, (hipStream_t)stream);
+}
+
+extern "C" int hdiff_pack_conv_weight_h2_words(int Cout, int Cin, int CoutPad, int64_t* words_out) {
+  HDIFF_CHECK_ARG(words_out, "pack_conv_weight_h2_words: null pointer");
+  HDIFF_CHECK_ARG(Cout > 0 && Cin > 0 && Cin % 16 == 0 && CoutPad >= Cout && CoutPad % 64 == 0,
+                  "pack_conv_weight_h2_words: needs Cin %% 16 == 0 and CoutPad %% 64 == 0 (Cin %d, Cout %d, CoutPad %d)", Cin, Cout, CoutPad);
+  *words_out = (int64_t)(Cin / 16) * 9 * 2 * CoutPad * 8 + 4;
+  return HDIFF_OK;
+}
+
+extern "C" int hdiff_pack_conv_weight_h2(const float* w, void* wp2, int Cout, int Cin, int CoutPad, hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(w && wp2, "pack_conv_weight_h2: null pointer");
+  HDIFF_CHECK_ARG(Cout > 0 && Cin > 0 && Cin % 16 == 0 && CoutPad >= Cout && CoutPad % 64 == 0,
+                  "pack_conv_weight_h2: needs Cin %% 16 == 0 and CoutPad %% 64 == 0 (Cin %d, Cout %d, CoutPad %d)", Cin, Cout, CoutPad);
+  PackX3K q{};
+  q.mode = 0; q.Cout = Cout; q.Cin = Cin; q.KH = 3; q.KW = 3; q.ntaps = 9; q.CoutPad = CoutPad;
+  for (int t = 0; t < 9; ++t) { q.ky[t] = t / 3; q.kx[t] = t % 3; }
+  const size_t n = (size_t)(Cin / 16) * 9 * CoutPad * 8, nw = (size_t)Cout * Cin * 9;
+  unsigned* tail = (unsigned*)wp2 + 2 * n;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  const int mblocks = (int)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024);
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  if (hipMemsetAsync(tail, 0, 16, (hipStream_t)stream) != hipSuccess) {
+    hdiff::set_error("pack_conv_weight_h2: hipMemsetAsync failed");
+    return HDIFF_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(conv_weight_absmax_kernel, dim3(mblocks), dim3(256), 0, (hipStream_t)stream, w, nw, tail);
+  HDIFF_CHECK_LAUNCH("conv_weight_absmax_kernel");
+  hipLaunchKernelGGL(pack_conv_weight_h2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned*)wp2, q, 1.0f);
+  HDIFF_CHECK_LAUNCH("pack_conv_weight_h2_kernel");
+  return HDIFF_OK;
+}
+
+extern "C" int hdiff_gn_act_scale(const float* gamma, const float* beta, int C, int64_t group_elems, float gain, float* out2,
+                                  hdiff_stream_t stream) {
+  HDIFF_CHECK_ARG(gamma && beta && out2, "gn_act_scale: null pointer");
+  HDIFF_CHECK_ARG(C > 0 && group_elems > 0 && gain >= 1.0f && gain <= 1024.0f, "gn_act_scale: bad sizes (C %d, gain %g)", C, (double)gain);
+  (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+  hipLaunchKernelGGL(gn_act_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gamma, beta, C,
+                     sqrtf((float)(group_elems > 1 ? group_elems - 1 : 1)), gain, out2);
+  HDIFF_CHECK_LAUNCH("gn_act_scale_kernel");
+  return HDIFF_OK;
 }
 
 extern "C" int hdiff_pack_conv_weight_x3_taps(const float* w, void* wp3, int mode, int Cout, int Cin, int KH, int KW, int ntaps,

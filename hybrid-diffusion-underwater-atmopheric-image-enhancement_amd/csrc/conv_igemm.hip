@@ -12,6 +12,8 @@
 // fetched one (tap, k-pair) step ahead of the MFMAs that consume them.
 // Each wave owns 64 channels x (32*WN) pixels: 2 x WN accumulators of 32x32 (16 VGPRs each).
 // fp32 MFMA is exact fp32 (a k-ordered fma chain), so results differ from the reference only by summation order.
+#include <stdlib.h>
+
 #include "common.h"
 
 using namespace hdiff;
@@ -633,8 +635,16 @@ namespace {
 // grid = input grid) and the output-parity phases of ConvTranspose2d(5, stride 2) (9 / 6 / 6 / 4 taps, output pixel
 // (2y + py, 2x + px)) -- with 16-channel-aligned inputs and a launch large enough to fill the chip (small ones keep the
 // split-K path of the fp32 kernel).
+// The fp16-pair form of that kernel (conv3x3_x3.hip, PAIR): the plain 3x3 conv whose input range the caller knows -- behind the
+// GroupNorm + Swish prologue (or an activation tensor made from it), bounded by the GroupNorm weights (act_scale from
+// hdiff_gn_act_scale, weights from hdiff_pack_conv_weight_h2).
+bool is_h2_conv_shape(const hdiff_conv_desc* d, bool same) {
+  static const char* e = getenv("HDIFF_CONV");       // dev knob: "bf16x3" keeps the bf16-triple kernel everywhere
+  if (e && strcmp(e, "bf16x3") == 0) return false;
+  return same && d->ntaps == 9 && d->wp_h2 != nullptr && d->act_scale != nullptr;
+}
 bool is_x3_conv(const hdiff_conv_desc* d) {
-  if (d->wp_x3 == nullptr || hdiff::contraction_mode() != HDIFF_CONTRACT_BF16X3) return false;
+  if ((d->wp_x3 == nullptr && d->wp_h2 == nullptr) || hdiff::contraction_mode() != HDIFF_CONTRACT_BF16X3) return false;
   if ((d->ntaps != 9 && d->ntaps != 6 && d->ntaps != 4) || d->in_stride != 1) return false;
   if (d->VH != d->H || d->VW != d->W) return false;
   const bool same = d->out_sy == 1 && d->out_oy == 0 && d->out_sx == 1 && d->out_ox == 0 && d->OH == d->H && d->OW == d->W;
@@ -658,7 +668,8 @@ bool is_x3_conv(const hdiff_conv_desc* d) {
   const int Cin = d->C0 + d->C1;
   if (Cin % 16 != 0 || (d->C1 != 0 && d->C0 % 16 != 0) || Cin > 4096) return false;
   const long blocks = (long)cdiv(d->W, 32) * cdiv(d->H, 8) * cdiv(d->Cout, 64) * d->B;
-  return blocks >= 192;
+  if (blocks < 192) return false;
+  return d->wp_x3 != nullptr || is_h2_conv_shape(d, same);
 }
 
 // A plain 1x1 / stride-1 conv over a full-size output with no GroupNorm prologue and enough pixels to fill the chip goes to
@@ -680,6 +691,15 @@ extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream)
     hdiff::ConvX3K q{};
     q.x0 = d->x0; q.x1 = d->x1; q.C0 = d->C0; q.C1 = d->C1; q.Cin = d->C0 + d->C1; q.H = d->H; q.W = d->W;
     q.wp3 = (const unsigned*)d->wp_x3; q.CoutPad = d->CoutPad; q.Cout = d->Cout;
+    {
+      const bool same = d->out_sy == 1 && d->out_oy == 0 && d->out_sx == 1 && d->out_ox == 0 && d->OH == d->H && d->OW == d->W;
+      if (is_h2_conv_shape(d, same)) {         // fp16 pairs (three products) instead of bf16 triples (six)
+        q.wp3 = (const unsigned*)d->wp_h2;
+        q.act_scale = d->act_scale;
+        q.w_scale = reinterpret_cast<const float*>(q.wp3 + (size_t)(q.Cin / 16) * 9 * 2 * d->CoutPad * 8);
+        q.one = 1.0f;
+      }
+    }
     q.bias = d->bias; q.gn_scale = d->gn_scale; q.gn_shift = d->gn_shift; q.addvec = d->addvec; q.residual = d->residual;
     q.out = d->out; q.tiles_x = cdiv(d->W, 32); q.ntaps = d->ntaps;
     for (int t = 0; t < d->ntaps; ++t) q.tap_off[t] = ((d->tap_dy[t] + 1) * 34 + (d->tap_dx[t] + 1)) * 4;

@@ -94,6 +94,24 @@ class PackedConv:
         self._x3_src: Optional[torch.Tensor] = None
         self._x3_transposed = False
         self._x3_taps: Optional[Tuple[int, int, int]] = None
+        self.wp2: Optional[torch.Tensor] = None      # fp16-pair copy + the staged activations' power of two, see enable_h2
+        self.act_scale: Optional[torch.Tensor] = None
+        self._h2_src: Optional[torch.Tensor] = None
+        self._h2_gn: Optional[Tuple[torch.Tensor, torch.Tensor, int, float]] = None
+
+    def enable_h2(self, w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, group_elems: int, gain: float = 1.0) -> None:
+        """Also keep the weights as two fp16 pieces (conv3x3_x3.hip, PAIR) for a plain 3x3 conv whose input is the output of
+        GroupNorm(gamma, beta) + Swish over groups of ``group_elems`` elements, times ``gain`` (1 / keep behind a dropout):
+        that output is bounded by sqrt(n - 1) max|gamma| + max|beta|, which fixes the power of two the activations are staged
+        with (hdiff_gn_act_scale, evaluated at pack time like the weights)."""
+        if self.ntaps == 9 and self.cin % 16 == 0 and tuple(w.shape[2:]) == (3, 3) and self.wp2 is None:
+            words = C.c_int64(0)
+            _capi.check(_capi.lib().hdiff_pack_conv_weight_h2_words(self.cout, self.cin, self.cout_pad, C.byref(words)),
+                        "pack_conv_weight_h2_words")
+            self.wp2 = torch.empty(words.value, dtype=torch.int32, device=self.wp.device)
+            self.act_scale = torch.empty(2, dtype=torch.float32, device=self.wp.device)
+            self._h2_src = w
+            self._h2_gn = (gamma, beta, int(group_elems), float(gain))
 
     def enable_x3(self, w: torch.Tensor, transposed: bool = False) -> None:
         """Also keep the weights as three bf16 pieces (conv3x3_x3.hip) -- used when the contraction mode is bf16x3.
@@ -135,6 +153,12 @@ class PackedConv:
         elif self.wp3 is not None:
             _capi.check(lib.hdiff_pack_conv_weight_x3(self._x3_src.data_ptr(), self.wp3.data_ptr(), self.cout, self.cin,
                                                       self.cout_pad, int(self._x3_transposed), stream), "pack_conv_weight_x3")
+        if self.wp2 is not None:
+            gamma, beta, group_elems, gain = self._h2_gn
+            _capi.check(lib.hdiff_pack_conv_weight_h2(self._h2_src.data_ptr(), self.wp2.data_ptr(), self.cout, self.cin,
+                                                      self.cout_pad, stream), "pack_conv_weight_h2")
+            _capi.check(lib.hdiff_gn_act_scale(gamma.data_ptr(), beta.data_ptr(), int(gamma.numel()), C.c_int64(group_elems),
+                                               C.c_float(gain), self.act_scale.data_ptr(), stream), "gn_act_scale")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -150,6 +174,7 @@ class Plan:
         self.lib = _capi.lib()
         self.ops: List[Tuple[str, Callable, tuple]] = []
         self.packs: List[PackedConv] = []
+        self._gn_src: Dict[int, Tuple[torch.Tensor, torch.Tensor, int, float]] = {}   # id(gn scale buffer) -> its GroupNorm
         self._pool: Dict[int, List[torch.Tensor]] = {}
         self._all: List[torch.Tensor] = []
         self._keep: List[object] = []
@@ -238,7 +263,11 @@ class Plan:
     def conv(self, x0: torch.Tensor, x1: Optional[torch.Tensor], pk: PackedConv, bias: Optional[torch.Tensor],
              out: torch.Tensor, *, B: int, H: int, W: int, VH: int, VW: int, in_stride: int = 1,
              out_map: Tuple[int, int, int, int] = (1, 0, 1, 0), gn: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-             addvec: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> None:
+             addvec: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+             act_range: Optional[Tuple[torch.Tensor, torch.Tensor, int, float]] = None) -> None:
+        """act_range = (gamma, beta, group_elems, gain): the input tensor itself is gain * swish(GroupNorm(gamma, beta)(.)) of
+        groups of group_elems elements (an activation materialised by the caller, e.g. behind a dropout mask) -- what the
+        fp16-pair 3x3 kernel needs to know about its range; with ``gn`` from gn_scale_shift() the plan knows it already."""
         d = _capi.ConvDesc()
         C0 = int(x0.shape[1])
         C1 = int(x1.shape[1]) if x1 is not None else 0
@@ -254,6 +283,13 @@ class Plan:
         d.out_sy, d.out_oy, d.out_sx, d.out_ox = out_map
         d.ntaps = pk.ntaps
         d.wp_x3 = _ptr(pk.wp3)
+        if act_range is None and gn is not None:
+            act_range = self._gn_src.get(id(gn[0]))
+        if act_range is not None and pk.wp3 is not None and pk._x3_taps is None and not pk._x3_transposed and in_stride == 1 \
+                and out_map == (1, 0, 1, 0):
+            # a plain 3x3 conv behind GroupNorm + Swish: the fp16-pair form of the split-operand kernel (its input range is known)
+            pk.enable_h2(pk._x3_src, *act_range)
+        d.wp_h2, d.act_scale = _ptr(pk.wp2), _ptr(pk.act_scale)
         for i in range(pk.ntaps):
             d.tap_dy[i], d.tap_dx[i] = pk.taps.dy[i], pk.taps.dx[i]
         need = C.c_int64(0)
@@ -292,6 +328,7 @@ class Plan:
                   gamma.data_ptr(), beta.data_ptr(), C.c_float(GN_EPS), scale.data_ptr(), shift.data_ptr())
         self.keep((x0, x1, gamma, beta, ws))
         self.free(ws)
+        self._gn_src[id(scale)] = (gamma, beta, (Ct // GN_GROUPS) * HW, 1.0)     # for conv(): the range of swish(gn(x))
         return scale, shift
 
     def block_vec(self, temb: torch.Tensor, cemb: Optional[torch.Tensor], P: Dict[str, torch.Tensor], p: str, B: int,

@@ -75,6 +75,19 @@ int hdiff_pack_conv_weight_x3(const float* w, void* wp3, int Cout, int Cin, int 
  * wp3 holds (Cin/16)*ntaps*3*CoutPad*8 32-bit words. */
 int hdiff_pack_conv_weight_x3_taps(const float* w, void* wp3, int mode, int Cout, int Cin, int KH, int KW, int ntaps,
                                    const int* tap_ky, const int* tap_kx, int CoutPad, hdiff_stream_t stream);
+/* (ABI 5) Weights of a standard 3x3 conv ([Cout][Cin][3][3], Cin % 16 == 0) as TWO fp16 pieces of w * 2^t, t chosen on the
+ * device so that max |w| 2^t lies in [2^14, 2^15): [Cin/16][tap][piece][CoutPad][16] followed by a 4-word tail
+ * {scratch, 2^-t, 2^t, 0}; hdiff_pack_conv_weight_h2_words gives the size in 32-bit words.  For the fp16-pair form of the
+ * split-operand 3x3 kernel (hdiff_conv_desc.wp_h2; replaces the weight operand of F.conv2d at ModelCondition.py:172, 186). */
+int hdiff_pack_conv_weight_h2_words(int Cout, int Cin, int CoutPad, int64_t* words_out);
+int hdiff_pack_conv_weight_h2(const float* w, void* wp2, int Cout, int Cin, int CoutPad, hdiff_stream_t stream);
+/* (ABI 5) Range of a GroupNorm + Swish output from the GroupNorm weights alone: |swish(gamma * xhat + beta)| <=
+ * sqrt(n - 1) * max |gamma| + max |beta| =: A for groups of n = group_elems elements (a normalised value cannot leave
+ * [-sqrt(n - 1), sqrt(n - 1)]).  out2[0] = 2^s, out2[1] = 2^-s with gain * A * 2^s in [2^13, 2^14): the power of two by which
+ * the fp16-pair conv stages its activations (hdiff_conv_desc.act_scale); gain = 1, or 1 / keep when a dropout mask scaled by
+ * 1 / keep sits between the activation and the conv (ModelCondition.py:185).  nn.GroupNorm at ModelCondition.py:169, 182. */
+int hdiff_gn_act_scale(const float* gamma, const float* beta, int C, int64_t group_elems, float gain, float* out2,
+                       hdiff_stream_t stream);
 
 typedef struct hdiff_conv_desc {
   /* input: virtual channel-concat of x0 [B][C0][H][W] and x1 [B][C1][H][W] (x1 may be NULL with C1 = 0);
@@ -115,6 +128,15 @@ typedef struct hdiff_conv_desc {
    * repeated tap, runs the fp32 kernel on wp instead); a pack made by hdiff_pack_conv_weight_x3_taps holds the taps in
    * the order of the list it was given, and the descriptor has to list them in that same order. */
   const void* wp_x3;
+  /* optional (ABI 5): the fp16-pair form of the same kernel for the plain 3x3 / pad-1 conv WITH the GroupNorm + Swish prologue
+   * (three fp16 piece products instead of six bf16 ones).  wp_h2 = hdiff_pack_conv_weight_h2 of the same weights, act_scale =
+   * the two floats of hdiff_gn_act_scale for the GroupNorm whose statistics gn_scale / gn_shift carry.  Preferred over wp_x3
+   * when both are set, the mode is HDIFF_CONTRACT_BF16X3 and the launch qualifies; either may be NULL.  act_scale is the
+   * caller's statement that every staged activation (after the prologue, if any) is below 2^15 / act_scale[0] in magnitude:
+   * with gn_scale / gn_shift that are not GroupNorm statistics of x0 / x1 a value can exceed it, the fp16 conversion then gives
+   * inf and the output NaN (never silently wrong). */
+  const void* wp_h2;
+  const float* act_scale;
 } hdiff_conv_desc;
 
 int hdiff_conv2d_fwd_workspace(const hdiff_conv_desc* d, int64_t* floats_out);

@@ -434,6 +434,136 @@ def test_conv3x3_split_bf16_is_fp32_class(C0, C1, cout, H, W, B, use_gn, bf16x3_
     assert rms(got_x3) <= 1.5 * rms(got_f32) + 1e-12, (rms(got_x3), rms(got_f32))
 
 
+def run_conv_gn(x0, x1, gamma, beta, w, b, addvec=None, residual=None, pairs=True):
+    """GroupNorm statistics -> fused GroupNorm / Swish prologue -> 3x3 conv through the plan, as the U-Net emits it; with
+    ``pairs`` the conv may take the fp16-pair kernel (bf16x3 mode), without it the plan forgets where the statistics came from
+    and the bf16-triple kernel runs."""
+    plan = E.Plan(DEV)
+    B, C0, H, W = x0.shape
+    dg = lambda t: None if t is None else t.to(DEV).contiguous()
+    d_x0, d_x1, d_gamma, d_beta = dg(x0), dg(x1), dg(gamma), dg(beta)
+    pk = E._std_pack(plan, w.to(DEV), 3, 1)
+    out = plan.buf(B, w.shape[0], H, W)
+    gn = plan.gn_scale_shift(d_x0, d_x1, d_gamma, d_beta, B, H * W)
+    if not pairs:
+        plan._gn_src.clear()
+    plan.conv(d_x0, d_x1, pk, dg(b), out, B=B, H=H, W=W, VH=H, VW=W, gn=gn, addvec=dg(addvec), residual=dg(residual))
+    assert (pk.wp2 is not None) == pairs
+    plan.pack_weights()
+    plan.run()
+    torch.cuda.synchronize()
+    return out.clone()
+
+
+def _gn_swish_conv_f64(x0, x1, gamma, beta, w, b, addvec, residual):
+    xin = (x0 if x1 is None else torch.cat([x0, x1], dim=1)).double()
+    a = F.group_norm(xin, 32, gamma.double(), beta.double(), eps=1e-5)
+    a = a * torch.sigmoid(a)
+    want = F.conv2d(a, w.double(), None if b is None else b.double(), padding=1)
+    if addvec is not None:
+        want = want + addvec.double()[:, :, None, None]
+    if residual is not None:
+        want = want + residual.double()
+    return want
+
+
+@pytest.mark.parametrize("C0,C1,cout,H,W,B", [(64, 0, 64, 64, 64, 16), (128, 64, 128, 64, 96, 4), (256, 0, 256, 32, 32, 12),
+                                               (128, 0, 128, 128, 128, 2)])
+def test_conv3x3_fp16_pairs_is_fp32_class(C0, C1, cout, H, W, B, bf16x3_mode):
+    """conv3x3_x3.hip, PAIR: the plain 3x3 conv behind GroupNorm + Swish with both operands as fp16 pairs staged at a power of
+    two fixed by the GroupNorm weights (three products instead of six).  Error against float64 in the class of the fp32-MFMA
+    kernel's (the bf16-triple kernel's gate) and not above the bf16-triple kernel's own; concat input, channels with very
+    different scales and offsets, bias + vector + residual epilogue."""
+    lib = bf16x3_mode
+    g = torch.Generator().manual_seed(C0 * 5 + cout + H)
+    cin = C0 + C1
+    chan = lambda c: torch.exp(torch.randn(1, c, 1, 1, generator=g) * 1.5)
+    x0 = torch.randn(B, C0, H, W, generator=g) * chan(C0) + torch.randn(1, C0, 1, 1, generator=g) * 3
+    x1 = torch.randn(B, C1, H, W, generator=g) * chan(C1) if C1 else None
+    gamma, beta = torch.rand(cin, generator=g) * 1.5 + 0.25, torch.randn(cin, generator=g) * 0.5
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b, vec, res = torch.randn(cout, generator=g), torch.randn(B, cout, generator=g), torch.randn(B, cout, H, W, generator=g)
+    want = _gn_swish_conv_f64(x0, x1, gamma, beta, w, b, vec, res)
+    got_h2 = run_conv_gn(x0, x1, gamma, beta, w, b, vec, res)
+    got_x3 = run_conv_gn(x0, x1, gamma, beta, w, b, vec, res, pairs=False)
+    _capi.check(lib.hdiff_set_contraction_mode(0))
+    got_f32 = run_conv_gn(x0, x1, gamma, beta, w, b, vec, res, pairs=False)
+    _capi.check(lib.hdiff_set_contraction_mode(1))
+    assert not torch.equal(got_h2, got_x3) and not torch.equal(got_h2, got_f32), "the fp16-pair kernel did not run"
+    close(got_h2, want.float(), rel=1e-5, what="conv3x3 fp16 pairs")
+    rms = lambda t: (t.double().cpu() - want).pow(2).mean().sqrt().item()
+    worst = lambda t: (t.double().cpu() - want).abs().max().item()
+    print(f"conv3x3 {cin}->{cout} {H}x{W}: rms vs float64: pairs {rms(got_h2):.3e}, triples {rms(got_x3):.3e}, fp32-MFMA {rms(got_f32):.3e}")
+    assert rms(got_h2) <= 1.5 * rms(got_f32) + 1e-12, (rms(got_h2), rms(got_f32))
+    assert rms(got_h2) <= 1.25 * rms(got_x3) + 1e-12, (rms(got_h2), rms(got_x3))
+    assert worst(got_h2) <= 2.0 * worst(got_f32) + 1e-12, (worst(got_h2), worst(got_f32))
+
+
+@pytest.mark.parametrize("name", ["lone-spike", "huge-gamma", "tiny-gamma", "huge-weights", "tiny-weights"])
+def test_conv3x3_fp16_pairs_range(name, bf16x3_mode):
+    """The fp16 range of the PAIR kernel: a group whose only non-zero element is normalised to sqrt(n - 1) -- the largest value
+    GroupNorm can produce, the bound the staging power of two is made for --, GroupNorm weights and conv weights of extreme
+    magnitude.  Finite, and as close to float64 as the fp32-MFMA kernel."""
+    lib = bf16x3_mode
+    g = torch.Generator().manual_seed(11)
+    B, Cc, H, W = 16, 64, 64, 64          # 256 workgroups: large enough for the split-operand kernels
+    x = torch.randn(B, Cc, H, W, generator=g)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    w = torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(Cc * 9)
+    if name == "lone-spike":
+        x[:, :2] = 0.0
+        x[:, 0, 17, 23] = 5.0          # group 0 = channels 0, 1: xhat there is sqrt(2 * 4096 - 1) = 90.5
+        gamma[0], beta[0] = 2.0, 1.0
+    elif name == "huge-gamma":
+        gamma *= 3.0e4; beta *= 1.0e4
+    elif name == "tiny-gamma":
+        gamma *= 1.0e-6; beta *= 1.0e-6
+    elif name == "huge-weights":
+        w *= 1.0e12
+    elif name == "tiny-weights":
+        w *= 1.0e-12
+    want = _gn_swish_conv_f64(x, None, gamma, beta, w, None, None, None)
+    got = run_conv_gn(x, None, gamma, beta, w, None)
+    _capi.check(lib.hdiff_set_contraction_mode(0))
+    got_f32 = run_conv_gn(x, None, gamma, beta, w, None, pairs=False)
+    _capi.check(lib.hdiff_set_contraction_mode(1))
+    assert torch.isfinite(got).all()
+    assert not torch.equal(got, got_f32), "the fp16-pair kernel did not run"
+    scale = want.abs().max().item()
+    rms = lambda t: (t.double().cpu() - want).pow(2).mean().sqrt().item() / scale
+    worst = lambda t: (t.double().cpu() - want).abs().max().item() / scale
+    print(f"{name}: rms {rms(got):.3e} (fp32-MFMA {rms(got_f32):.3e}), worst {worst(got):.3e} ({worst(got_f32):.3e})")
+    assert rms(got) <= 1.5 * rms(got_f32) + 1e-12 and worst(got) <= 2.0 * worst(got_f32) + 1e-12
+
+
+def test_conv3x3_fp16_pairs_outside_the_stated_range_is_loud(bf16x3_mode):
+    """act_scale is the caller's statement about the staged activations' range; scale / shift that are not the statistics of
+    x break it -- the answer is then NaN, never a silently wrong number."""
+    g = torch.Generator().manual_seed(12)
+    B, Cc, H, W = 16, 64, 64, 64
+    x = torch.randn(B, Cc, H, W, generator=g)
+    gamma, beta = torch.ones(Cc), torch.zeros(Cc)
+    w = torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(Cc * 9)
+    d_x, d_gamma, d_beta = x.to(DEV), gamma.to(DEV), beta.to(DEV)
+    pre = E.Plan(DEV)                       # the statistics in a plan of their own: the conv plan below is run twice
+    gn = pre.gn_scale_shift(d_x, None, d_gamma, d_beta, B, H * W)
+    pre.run()
+    plan = E.Plan(DEV)
+    plan._gn_src[id(gn[0])] = pre._gn_src[id(gn[0])]
+    pk = E._std_pack(plan, w.to(DEV), 3, 1)
+    out = plan.buf(B, Cc, H, W)
+    plan.conv(d_x, None, pk, None, out, B=B, H=H, W=W, VH=H, VW=W, gn=gn)
+    assert pk.wp2 is not None
+    plan.pack_weights()
+    plan.run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    gn[0].mul_(1.0e4)                      # "statistics" of some other tensor: values up to 4e4 where the bound says 128
+    plan.run()
+    torch.cuda.synchronize()
+    assert torch.isnan(out).any()
+
+
 def test_linear_rows_and_gather():
     g = torch.Generator().manual_seed(1)
     table = torch.randn(20, 128, generator=g)

@@ -26,7 +26,7 @@ def header_symbols():
 
 def test_library_exports_every_declared_symbol():
     lib = hdiff_amd.lib()
-    assert lib.hdiff_abi_version() == 4
+    assert lib.hdiff_abi_version() == 5
     syms = header_symbols()
     assert len(syms) >= 25
     out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout

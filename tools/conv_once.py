@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch, hdiff_amd
 from hdiff_amd import engine as E
 B, Cin, Cout, S, k = [int(v) for v in (sys.argv[1:6] if len(sys.argv) > 5 else (4, 128, 128, 256, 3))]
-gn = len(sys.argv) > 6 and sys.argv[6] == "gn"
+gn = len(sys.argv) > 6 and sys.argv[6] in ("gn", "pairs")
+pairs = len(sys.argv) > 6 and sys.argv[6] == "pairs"       # real GroupNorm statistics: the fp16-pair kernel may run (bf16x3 mode)
 dev = "cuda:0"
 x = torch.randn(B, Cin, S, S, device=dev)
 w = torch.randn(Cout, Cin, k, k, device=dev) / math.sqrt(Cin * k * k)
@@ -13,6 +14,12 @@ plan = E.Plan(dev)
 pk = E._std_pack(plan, w, k, k // 2)
 out = plan.buf(B, Cout, S, S)
 g = (torch.rand(B, Cin, device=dev) + 0.5, torch.randn(B, Cin, device=dev)) if gn else None
+if pairs:
+    gamma, beta = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.3
+    pre = E.Plan(dev)
+    g = pre.gn_scale_shift(x, None, gamma, beta, B, S * S)
+    pre.run(); torch.cuda.synchronize()
+    plan._gn_src[id(g[0])] = (gamma, beta, (Cin // 32) * S * S, 1.0)
 plan.conv(x, None, pk, b, out, B=B, H=S, W=S, VH=S, VW=S, gn=g)
 plan.pack_weights()
 for _ in range(2): plan.run()
