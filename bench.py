@@ -640,16 +640,21 @@ def main():
                 avg = sum(conv_ms) / len(conv_ms)
                 fl = 2.0 * 9 * Cc * Cc * L_full * (2 * B)
                 ach = fl / (avg * 1e-3) / 1e12
-                cpeak = PEAK_F32_MFMA_TFLOPS if a.contract == "f32" else PEAK_BF16_MFMA_TFLOPS / 6
+                # the timed launches are the 3x3 convs behind GroupNorm + Swish: in the bf16x3 mode they run the fp16-pair form of
+                # the split-operand kernel, THREE 16-bit products per fp32 product (round 3's bf16 triples executed six)
+                cpeak = PEAK_F32_MFMA_TFLOPS if a.contract == "f32" else PEAK_BF16_MFMA_TFLOPS / 3
                 ckern = ("conv_igemm_kernel (fp32-input MFMA)" if a.contract == "f32" else
-                         "conv3x3_x3_kernel (six bf16 products per fp32 product: peak = bf16 dense MFMA peak / 6)")
+                         "conv3x3_x3_kernel<9, false, PAIR> (both operands as fp16 pairs, three products per fp32 product on the "
+                         "fp16 MFMA: peak = 16-bit dense MFMA peak / 3)")
                 roof["secondary"].append({
                     "bound": "mfma", "kernel": f"hdiff_conv2d_fwd = {ckern} 3x3 {Cc}->{Cc} at {S}x{S}, batch {2 * B} "
                                                "(GroupNorm-Swish prologue, bias/vector/residual epilogue)",
                     "achieved": round(ach, 2), "peak": round(cpeak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / cpeak, 4), "avg_launch_ms": round(avg, 3),
+                    "frac": round(ach / cpeak, 4),
+                    "frac_vs_peak_div6": None if a.contract == "f32" else round(ach / (PEAK_BF16_MFMA_TFLOPS / 6), 4),
+                    "avg_launch_ms": round(avg, 3),
                     "launches_timed": len(conv_ms), "algorithmic_flop_per_launch": fl,
-                    "traffic": traffic_tab.get(f"conv3x3_{Cc}_{S}_B{2 * B}") if a.contract == "f32" else None})
+                    "traffic": traffic_tab.get(f"conv3x3_{Cc}_{S}_B{2 * B}" + ("" if a.contract == "f32" else "_pairs"))})
             gn_ms = durations.get("gn_stats") or []
             if gn_ms:
                 avg = sum(gn_ms) / len(gn_ms)
@@ -667,9 +672,10 @@ def main():
             "metric": "denoising-steps/sec (256x256, T=1000)" if S == 256 else f"denoising-steps/sec ({S}x{S}, T=1000)",
             "value": world * K / elapsed, "unit": "denoising-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.contract == "f32" else "f32 (tensors and accumulation fp32; products of the attention scores and "
-                     "the 3x3 convs as 3xbf16 pieces, of attention's P.V as 2xfp16 pieces, on the 16-bit MFMA; fp32-class error: "
-                     "golden suite green at the fp32 tolerances, per-kernel error vs float64 <= 1.25x the fp32-MFMA kernel's)",
+            "dtype": "f32" if a.contract == "f32" else "f32 (tensors and accumulation fp32; products of the attention scores as "
+                     "3xbf16 pieces, of attention's P.V and of the 3x3 convs behind GroupNorm as 2xfp16 pieces, on the 16-bit MFMA; "
+                     "fp32-class error: golden suite green at the fp32 tolerances, per-kernel error vs float64 <= 1.25x (attention) / "
+                     "1.5x (conv) the fp32-MFMA kernel's)",
             "data": "synthetic",
             "config": {"workload": f"CFG-DDPM sampling, {S}x{S}, T=1000 linear schedule (1e-4..0.02), w={GUIDANCE_W}, "
                                    f"batch {B}/GPU (2x{B} UNet forwards per step), default UNet ch=128 ch_mult=[1,2,2,2] "

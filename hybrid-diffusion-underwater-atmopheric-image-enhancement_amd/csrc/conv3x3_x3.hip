@@ -40,6 +40,9 @@ using namespace hdiff;
 
 namespace {
 
+#ifndef CONVH2_ABL
+#define CONVH2_ABL 0   // dev: timing ablations of the fp16-pair form (wrong results with any bit set; tools/README.md): 1 no staging of
+#endif                 // the next chunk, 2 no weight loads in the loop, 4 no barrier, 8 no B operand reads in the loop, 16 no Swish
 constexpr int THREADS = 256;
 constexpr int PH = 10, PW = 34, PPIX = PH * PW;      // patch of an 8 x 32 tile
 constexpr int NSLOT = (4 * PPIX + THREADS - 1) / THREADS;   // (channel quad, pixel) staging slots per thread: 6
@@ -105,8 +108,19 @@ __global__ __launch_bounds__(THREADS, OCC) void conv3x3_x3_kernel(const ConvX3K 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int b = blockIdx.z;
-  const int co0 = blockIdx.y * 64;
-  const int tile_y = blockIdx.x / p.tiles_x, tile_x = blockIdx.x - tile_y * p.tiles_x;
+  // Workgroup -> (pixel tile, channel block).  The channel blocks of ONE pixel tile read the same activation patch; in grid
+  // order they are a whole plane of tiles apart and each fetched it from HBM again (measured on the fp32 kernel: input bytes x
+  // Cout / 64).  Workgroups go to the 8 XCDs round robin by linear id, so the channel blocks of a tile are given linear ids
+  // 8 apart: same XCD, consecutive in time -- the later ones find the patch in that XCD's L2.
+  int tile_id = blockIdx.x, cob = blockIdx.y;
+  if ((gridDim.x & 7u) == 0u && gridDim.y > 1u) {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, per = 8u * gridDim.y;
+    const unsigned grp = lin / per, r = lin - grp * per;
+    tile_id = (int)(grp * 8u + (r & 7u));
+    cob = (int)(r >> 3);
+  }
+  const int co0 = cob * 64;
+  const int tile_y = tile_id / p.tiles_x, tile_x = tile_id - tile_y * p.tiles_x;
   const int vy0 = tile_y * 8, vx0 = tile_x * 32;
   const bool has_gn = p.gn_scale != nullptr;
   const size_t HW = (size_t)p.H * p.W;
@@ -149,7 +163,21 @@ __global__ __launch_bounds__(THREADS, OCC) void conv3x3_x3_kernel(const ConvX3K 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-  f32x4 xv[NSLOT];
+  // XAHEAD (the fp16-pair form): the patch of chunk c + 2 is requested at the START of chunk c into a second register set and
+  // moved over at its end -- requested at the end of chunk c (the bf16-triple form, whose taps take twice as long) the first
+  // staging slot of chunk c + 1 consumed its load 400 cycles after it had left.
+  constexpr bool XAHEAD = PAIR;
+  f32x4 xv[NSLOT], xv2[XAHEAD ? NSLOT : 1];
+  auto issue_loads_to = [&](f32x4 (&dst)[XAHEAD ? NSLOT : 1], int c0) {
+    const float* xbase = (c0 < p.C0) ? p.x0 + ((size_t)b * p.C0 + c0) * HW : p.x1 + ((size_t)b * p.C1 + (c0 - p.C0)) * HW;
+#pragma unroll
+    for (int i = 0; i < (XAHEAD ? NSLOT : 0); ++i) {
+      const bool ok = s_goff[i] >= 0;
+      const float* src = xbase + (size_t)(4 * s_quad[i]) * HW + (ok ? s_goff[i] : 0);
+      const float v0 = src[0], v1 = src[HW], v2 = src[2 * HW], v3 = src[3 * HW];
+      dst[i] = f32x4{ok ? v0 : 0.f, ok ? v1 : 0.f, ok ? v2 : 0.f, ok ? v3 : 0.f};
+    }
+  };
   auto issue_loads = [&](int c0) {
     // a 16-channel chunk never straddles the concat seam (C0 % 16 == 0 is checked on the host)
     const float* xbase = (c0 < p.C0) ? p.x0 + ((size_t)b * p.C0 + c0) * HW : p.x1 + ((size_t)b * p.C1 + (c0 - p.C0)) * HW;
@@ -174,7 +202,7 @@ __global__ __launch_bounds__(THREADS, OCC) void conv3x3_x3_kernel(const ConvX3K 
       const bool inside = s_goff[i] >= 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float gk = swish_fast(fmaf(v[k], sc[k], sh[k]));
+        const float gk = (PAIR && (CONVH2_ABL & 16)) ? fmaf(v[k], sc[k], sh[k]) : swish_fast(fmaf(v[k], sc[k], sh[k]));
         v[k] = inside ? gk : 0.f;
       }
     }
@@ -237,31 +265,49 @@ __global__ __launch_bounds__(THREADS, OCC) void conv3x3_x3_kernel(const ConvX3K 
   // Chunk loop, ONE barrier per chunk: while the matrix core works through chunk c (LDS buffer c & 1), the vector pipe turns
   // the raw patch of chunk c + 1 (in registers since the previous chunk) into split pieces in the other buffer, one or two
   // staging slots behind every tap's MFMAs; the global loads of chunk c + 2 leave once those registers are free.
+  // The weight operands form ONE stream over (chunk, tap), two taps ahead of their use, through a ring of three register sets
+  // (WSTREAM: a tap count that is a multiple of three keeps the ring's phase from chunk to chunk; before, every chunk began by
+  // requesting its first two taps and waiting for them -- with half the matrix time per tap the fp16-pair form spent 38 % of
+  // its wave time waiting, SQ_WAIT_ANY).
+  constexpr bool WSTREAM = (NT % 3 == 0);
+  u32x4 w[3][NP];
   auto chunk = [&](auto gn_tag, auto more_tag, int c, int nchunks) {
     constexpr bool more = decltype(more_tag)::value;      // compile time: the staging must not sit in a block of its own
     const unsigned* sX = sXbuf[c & 1];
     unsigned* sNext = sXbuf[(c + 1) & 1];
-    u32x4 w[3][NP], xp[2][NP];
-    load_w(w[0], c, 0);
-    load_w(w[1], c, 1);
+    u32x4 xp[2][NP];
+    if (XAHEAD && c + 2 < nchunks) issue_loads_to(xv2, (c + 2) * 16);
+    if (!WSTREAM || c == 0) {
+      load_w(w[0], c, 0);
+      load_w(w[1], c, 1);
+    }
     load_x(xp[0], sX, 0, 0);
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
-      if (tap + 2 < NT) load_w(w[(tap + 2) % 3], c, tap + 2);
+      if (PAIR && (CONVH2_ABL & 2)) {
+      } else if (tap + 2 < NT) load_w(w[(tap + 2) % 3], c, tap + 2);
+      else if (WSTREAM && more) load_w(w[(tap + 2) % 3], c + 1, tap + 2 - NT);      // the next chunk's first two taps
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int u = tap * 4 + nt;
-        if (u + 1 < 4 * NT) load_x(xp[(u + 1) & 1], sX, (u + 1) / 4, (u + 1) % 4);
-        mma_unit(w[tap % 3], xp[u & 1], nt);
+        if (u + 1 < 4 * NT && !(PAIR && (CONVH2_ABL & 8))) load_x(xp[(u + 1) & 1], sX, (u + 1) / 4, (u + 1) % 4);
+        mma_unit(w[tap % 3], xp[(PAIR && (CONVH2_ABL & 8)) ? 0 : (u & 1)], nt);
       }
-      if (more && tap < NSLOT) stage_slot(gn_tag, tap, (c + 1) * 16, sNext);
+      if (more && tap < NSLOT && !(PAIR && (CONVH2_ABL & 1))) stage_slot(gn_tag, tap, (c + 1) * 16, sNext);
     }
     if (more) {
 #pragma unroll
       for (int i = NT; i < NSLOT; ++i) stage_slot(gn_tag, i, (c + 1) * 16, sNext);     // fewer taps than staging slots
     }
-    if (c + 2 < nchunks) issue_loads((c + 2) * 16);
-    __syncthreads();
+    if constexpr (XAHEAD) {
+      if (c + 2 < nchunks) {
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) xv[i] = xv2[i];
+      }
+    } else {
+      if (c + 2 < nchunks) issue_loads((c + 2) * 16);
+    }
+    if (!(PAIR && (CONVH2_ABL & 4))) __syncthreads();
   };
 
   const int nchunks = p.Cin / 16;

@@ -17,18 +17,20 @@ import bench
 
 # key in the table            kernel-name filter         pass dirs prefix   wide loads   kernel sources
 ENTRIES = (
-    ("mha_flash_fwd_L65536_B16_bf16x3", "mha_flash_fwd_x3_kernelILi16", "x3", True, ["attention_x3.hip", "attention_x3p.hip", "common.h"]),
+    ("mha_flash_fwd_L65536_B16_bf16x3", "mha_flash_fwd_h2_kernel", "x3", True, ["attention_h2.hip", "attention_x3p.hip", "common.h"]),
     ("mha_flash_fwd_L65536_B16", "fast_kernel<16", "attn", True, ["attention.hip", "common.h"]),
     ("conv3x3_128_256_B16", "igemm_kernel<2, 8, 12, 5, 1", "conv", False, ["conv_igemm.hip", "common.h"]),
     ("gn_stats_128_256_B16", "gn_stats_kernel", "gn", True, ["groupnorm.hip", "common.h"]),
-    ("mha_flash_bwd_L65536_B4_bf16x3", "mha_bwd_x3_kernel", "bwd", True, ["attention_bwd_x3.hip", "attention_bwd.hip", "common.h"]),
+    ("conv3x3_128_256_B16_pairs", "conv3x3_x3_kernel", "convh2", False, ["conv3x3_x3.hip", "conv_igemm.hip", "common.h"]),
+    ("mha_flash_bwd_L65536_B4_bf16x3", "mha_bwd_h2_kernel", "bwd", True, ["attention_bwd_h2.hip", "attention_bwd.hip", "common.h"]),
     ("mha_flash_bwd_L65536_B4", "bwd_fused", "bwdf32", True, ["attention_bwd.hip", "common.h"]),
 )
 ALGORITHMIC = {
-    "mha_flash_fwd_L65536_B16_bf16x3": 3 * 16 * 128 * 65536 * 6 + 16 * 128 * 65536 * 4,   # q, k, v as bf16 pieces (6 B per element) read, o written
+    "mha_flash_fwd_L65536_B16_bf16x3": 16 * 128 * 65536 * (6 + 6 + 4 + 4),   # main kernel (round 4): q, k as bf16 triples (6 B per element), v as an fp16 pair (4 B) read, o written
+    "conv3x3_128_256_B16_pairs": 1074331648,
     "mha_flash_fwd_L65536_B16": 2147483648, "conv3x3_128_256_B16": 1074331648, "gn_stats_128_256_B16": 536870912,
     "mha_flash_bwd_L65536_B4": 4 * 65536 * 128 * 4 * 8,      # q, k, v, o, dO read; dq, dk, dv written: 8 tensors of B*C*L floats
-    "mha_flash_bwd_L65536_B4_bf16x3": 4 * 65536 * 128 * (5 * 6 + 3 * 4),   # main kernel: five piece tensors read (6 B per element), dq / dk / dv written
+    "mha_flash_bwd_L65536_B4_bf16x3": 4 * 65536 * 128 * (3 * 6 + 2 * 4 + 3 * 4),   # main kernel (round 4): q, k, k^T as bf16 triples, v, dO as fp16 pairs read, dq / dk / dv written
 }
 
 
