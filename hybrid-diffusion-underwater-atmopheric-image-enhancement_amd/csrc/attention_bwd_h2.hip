@@ -579,10 +579,10 @@ H2Geom h2_geometry(int B, int heads, int L, int D) {
   int want = cdiv(1024, B * heads);                      // ~2 rounds of 2 workgroups per CU on 256 CUs
   // At larger batches that leaves few key ranges per (sample, head) pair, and the workgroups of a pair are the ones that share
   // its Q / dO tile stream in their XCD's L2: up to 16 ranges per pair (batch 16: 567 -> 553 ms per launch; 32: 547) as
-  // long as the slabs stay below 16 GiB.
+  // long as the slabs stay below the cap (16 GiB, or HDIFF_BWD_SLAB_GIB: mha_bwd_slab_cap_bytes).
   {
     const long long per_range = (long long)B * heads * D * L * 4;
-    int cap = (int)((16ll << 30) / per_range);
+    int cap = (int)(hdiff::mha_bwd_slab_cap_bytes() / per_range);
     int more = 16 < cap ? 16 : cap;
     if (more > want) want = more;
   }

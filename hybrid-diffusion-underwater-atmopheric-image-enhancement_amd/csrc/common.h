@@ -104,12 +104,17 @@ int contraction_mode();   // HDIFF_CONTRACT_*
 
 // Mutation switch of the parity suite's own sensitivity test (tests/test_gpu_mutation.py): a library built with
 // -DHDIFF_MUTANT=<mask> silently drops ONE lowest-order piece product (bf16 pieces 0 x 2: 2^-16 of the product) --
-// bit 0 in the split-bf16 3x3 convolution, bit 1 in the d_head 32 attention forward (attention_x3p.hip), bit 2 in the
+// bit 0 in the split-bf16 3x3 convolution (its fp16-pair form: the low five bits of every activation's second piece), bit 1 in the
+// d_head 32 attention forward (attention_x3p.hip), bit 2 in the
 // score product of the d_head 16 attention forward (attention_h2.hip).  The tightened model-level tests must FAIL on it.
 #ifndef HDIFF_MUTANT
 #define HDIFF_MUTANT 0
 #endif
 
+// Upper bound on the dQ partial slabs of the split-operand attention backward (it sets how many key ranges a (sample, head) pair
+// is cut into at large batches): 16 GiB, or HDIFF_BWD_SLAB_GIB gibibytes (1 ... 256; read once per process).  The workspace
+// query and both backward kernels use this one function, so they agree.
+long long mha_bwd_slab_cap_bytes();
 // attention_bwd_x3.hip: the attention backward at d_head 16 in the split-bf16 formulation (dispatched from attention_bwd.hip)
 bool mha_bwd_x3_shape_ok(int B, int C, int heads, int L);     // the shape alone (mode-independent)
 bool mha_bwd_x3_applicable(int B, int C, int heads, int L);   // shape AND the bf16x3 contraction mode

@@ -306,7 +306,9 @@ class Plan:
 
     def attention_workspace(self, B: int, Cc: int, heads: int, L: int) -> Optional[torch.Tensor]:
         """Scratch for hdiff_mha_flash_fwd_ws (the operands as bf16 pieces, written and read inside that one call when the
-        contraction mode is bf16x3): sized by the library from the shape alone, so a plan serves both modes."""
+        contraction mode is bf16x3): sized by the library from the shape alone; allocated only when the plan is built in that mode."""
+        if self.lib.hdiff_get_contraction_mode() != 1:      # f32 mode: the kernels never touch it (plans are keyed by the mode; a plan
+            return None                                     # built here and run in the other mode splits inside the loop, as without a workspace)
         need = C.c_int64(0)
         _capi.check(self.lib.hdiff_mha_flash_fwd_workspace(B, Cc, heads, L, C.byref(need)), "mha_flash_fwd_workspace")
         return self.buf((need.value + 3) // 4) if need.value > 0 else None

@@ -1,7 +1,8 @@
 """The parity suite's own sensitivity, demonstrated: a library that silently drops ONE lowest-order piece product (bf16
 pieces 0 x 2, i.e. 2^-16 of each product) in the split-bf16 3x3 convolution, in the d_head 32 attention forward and in the
-score product of the d_head 16 attention forward (csrc/common.h, HDIFF_MUTANT = 7; built by `make mutant`) must turn the
-float64 error-class tests of tests/test_gpu_ops.py RED.
+score product of the d_head 16 attention forward, and that masks 2^-16 of every staged activation in the fp16-pair 3x3
+convolution (csrc/common.h, HDIFF_MUTANT = 7; built by `make mutant`) must turn the float64 error-class tests of
+tests/test_gpu_ops.py RED.
 
 Why those tests and not the model-level ones (VERDICT round 3 asked for the latter): measured on this build
 (gpurun_out/r4_mut_measure.txt) the default UNet at 128x128 differs from the real reference's eps by
@@ -28,6 +29,7 @@ def test_a_dropped_low_order_piece_product_turns_the_error_class_tests_red():
     if not os.path.isfile(mutant) or os.path.getmtime(mutant) < max(os.path.getmtime(f) for f in src):
         mutant = _capi.build_mutant()
     targets = ["tests/test_gpu_ops.py::test_conv3x3_split_bf16_is_fp32_class",
+               "tests/test_gpu_ops.py::test_conv3x3_fp16_pairs_is_fp32_class",
                "tests/test_gpu_ops.py::test_flash_attention_split_bf16_is_fp32_class"]
     env = dict(os.environ, HDIFF_LIB=mutant)
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-rf", "-p", "no:cacheprovider"] + targets, cwd=ROOT, env=env,
@@ -38,6 +40,8 @@ def test_a_dropped_low_order_piece_product_turns_the_error_class_tests_red():
     conv = [l for l in failed if "test_conv3x3_split_bf16_is_fp32_class" in l]
     att_pre = [l for l in failed if "test_flash_attention_split_bf16_is_fp32_class" in l and "pre-split" in l]
     assert len(conv) == 4, (conv, out[-2000:])                               # every convolution shape
+    pairs = [l for l in failed if "test_conv3x3_fp16_pairs_is_fp32_class" in l]
+    assert len(pairs) == 4, (pairs, out[-2000:])                             # ... of the fp16-pair form too (2^-16 of every activation masked)
     assert any("16-" in l for l in att_pre) and any("32-" in l for l in att_pre), (att_pre, out[-2000:])   # both head widths
     assert len(att_pre) == 4, att_pre
     # and the same selection is green on the real library (the suite runs it anyway; here: same process environment)
