@@ -128,21 +128,33 @@ class ClockSampler:
 
     def __init__(self, device_index=0):
         import glob
-        self.freq, self.power = None, None
+        self.freq, self.power, self.dpm, self.card = None, None, None, None
         cards = sorted(glob.glob("/sys/class/drm/card*/device"))
         amd = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
-        if device_index < len(amd):
-            for h in sorted(glob.glob(os.path.join(amd[device_index], "hwmon", "hwmon*"))):
-                f = os.path.join(h, "freq1_input")
-                if os.path.exists(f):
-                    self.freq = f
+        # the sysfs card of THIS process's device: by PCI address (a box shows every GPU of its host under /sys, the process
+        # sees one of them -- card0 is usually somebody else's, idle, GPU)
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            pass
+        pick = [c for c in amd if want and os.path.basename(os.path.realpath(c)) == want]
+        if not pick and len(amd) == 1:
+            pick = amd
+        if pick:
+            self.card = pick[0]
+            for h in sorted(glob.glob(os.path.join(self.card, "hwmon", "hwmon*"))):
+                for fi in sorted(glob.glob(os.path.join(h, "freq*_input"))):
+                    lab = (self._read(fi.replace("_input", "_label")) or "").strip()
+                    if lab == "sclk" or (self.freq is None and lab == ""):
+                        self.freq = fi
                 for pn in ("power1_average", "power1_input"):
                     if os.path.exists(os.path.join(h, pn)):
                         self.power = os.path.join(h, pn)
                         break
-            self.dpm = os.path.join(amd[device_index], "pp_dpm_sclk")
-        else:
-            self.dpm = None
+            self.dpm = os.path.join(self.card, "pp_dpm_sclk")
+        self.want = want
         self.mhz, self.watts, self._stop, self._thread = [], [], False, None
 
     @staticmethod
@@ -188,9 +200,10 @@ class ClockSampler:
 
     def summary(self):
         if not self.mhz:
-            return {"sclk_mhz_mean": None, "note": "no readable engine-clock file under /sys/class/drm/card*/device (hwmon freq1_input / pp_dpm_sclk)"}
+            return {"sclk_mhz_mean": None, "note": f"no readable engine-clock file for PCI device {self.want} under /sys/class/drm/card*/device "
+                                                   "(hwmon freq*_input labelled sclk / pp_dpm_sclk)"}
         out = {"sclk_mhz_mean": round(sum(self.mhz) / len(self.mhz), 1), "sclk_mhz_min": min(self.mhz), "sclk_mhz_max": max(self.mhz),
-               "samples": len(self.mhz), "source": self.freq or self.dpm, "sampled": "during the timed region, 20 Hz"}
+               "samples": len(self.mhz), "source": self.freq or self.dpm, "pci": self.want, "sampled": "during the timed region, 20 Hz"}
         if self.watts:
             out["board_power_w_mean"] = round(sum(self.watts) / len(self.watts), 1)
         return out

@@ -2,7 +2,11 @@
 // all five products of attention_bwd.hip on v_mfma_f32_16x16x32_bf16, every fp32 operand carried as three bf16 pieces
 // (x = x0 + x1 + x2 exactly, six piece products i + j <= 2, fp32 accumulation -- the error class of an fp32 FMA chain, see
 // attention_x3.hip).  Same contract, layouts and dQ slab protocol as attention_bwd.hip (reference: autograd through
-// nn.MultiheadAttention, ModelCondition.py:189, 204-208, TrainCondition.py:60): no atomics, bitwise reproducible.
+// nn.MultiheadAttention, ModelCondition.py:189, 204-208, TrainCondition.py:60), with ONE difference in how a slab word is
+// accumulated: fire-and-forget L2 float adds (global_atomic_add_f32) instead of load + add + store.  Every slab word has an
+// exclusive owner -- one thread of one workgroup, which touches it once per key block in program order -- so the adds form
+// their sums in a fixed order although the adder sits in L2: bitwise reproducible (asserted by the tests), no lock, no
+// inter-workgroup protocol, and the old value never travels to the CU.
 //
 //   mha_bwd_split3_kernel   Q (pre-scaled by log2(e)/sqrt(d)), K, V, dO -> bf16 pieces, once per tensor, as rows
 //                           [L][D] (plus K^T [D][L], read once per key block): 5 piece tensors, 30 bytes per element.
@@ -18,7 +22,8 @@
 //       dQ^T += K^T dS^T                             dS crosses LDS once: the packed pieces are stored as they are
 //                                                    ([key][query], ds_write_b64) and read back transposed by the same
 //                                                    instruction -- no third split, no 2-byte stores
-//   dQ of a tile is summed over the four waves in a fixed order and added to the key range's slab (attention_bwd.hip).
+//   dQ of a tile is summed over the four waves in a fixed order and added to the key range's slab (plain store during the range's
+//   first key block, exclusive-owner L2 adds afterwards); mha_dq_reduce_x3_kernel sums the ranges in order.
 // Per 16x16 (query, key) tile at d 16: 15 bf16 MFMAs (240 matrix cycles) + ~210 vector cycles, against 20 fp32 MFMAs (640);
 // at d 32: 30 bf16 MFMAs beside the SAME vector work, against 40 fp32 MFMAs (1280) -- two 16-row M tiles in dV^T, dK^T, dQ^T,
 // whose transposed operands are fetched one M tile at a time (registers: 256, spills only outside the tile loop).
