@@ -42,6 +42,8 @@ constexpr float OVERFLOW_LIMIT = 1.2379400e27f;   // 2^90, as in attention.hip
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -63,6 +65,22 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& h0, unsigned&
 __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x16 mfma32h(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// (a, b) -> two packed fp16 pairs, a = h0.lo + h1.lo up to 2^-23 |a| (or 2^-25 absolute); attention_h2.hip.  `one` is 1.0f in a
+// register the compiler cannot see through (the residual must stay an fma: v_fma_mixlo / mixhi_f16).
+__device__ __forceinline__ void split2(float a, float b, float one, unsigned& h0, unsigned& h1) {
+  const f16x2 p = {(_Float16)a, (_Float16)b};
+  unsigned u = __builtin_bit_cast(unsigned, p);
+  asm("" : "+v"(u));
+  const f16x2 q = __builtin_bit_cast(f16x2, u);
+  const f16x2 r = {(_Float16)__builtin_fmaf(a, one, -(float)q[0]), (_Float16)__builtin_fmaf(b, one, -(float)q[1])};
+  h0 = u;
+  h1 = __builtin_bit_cast(unsigned, r);
+}
+constexpr float P_SHIFT = 8.0f;       // PVH: the reference point enters as P = 2^8 ...
+constexpr float P_TRIP = 32768.0f;    // ... and moves when a lane's 16 P values of one block sum to 2^15 (attention_h2.hip)
 
 // split-product terms kept (piece of K or V, piece of Q or P): all i + j <= 2, small terms last in the table
 __device__ constexpr int TERM_A[6] = {0, 1, 0, 2, 1, 0};
@@ -114,10 +132,23 @@ __global__ __launch_bounds__(THREADS) void qkv_split3_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int D>
+// PVH (round 4, d_head 32): P.V on fp16 PAIRS, as attention_h2.hip does at d_head 16 -- P = h0 + h1 by v_cvt_pk_f16_f32 +
+// v_fma_mixlo / mixhi_f16 (1.5 vector instructions per value instead of 5.5), V as two fp16 pieces of V 2^s with s per channel
+// row (launch_v_split_h2; O times 2^-s at the end), three products (v1 p0, v0 p1, v0 p0) instead of six; S = Q K^T stays on the
+// bf16 triples.  fp16 ends at 65 504, so the softmax reference MOVES: it starts at (first block's maximum - 8) and whenever a
+// lane's 16 P values of a block sum to 2^15 or more the wave recomputes that block from its S accumulator under a reference
+// that puts the row's maximum over the block at 2^8, after scaling O and l of that query by the exact power of two.  Rows that
+// do not need it get delta = 0 and the same bits.  Each of a lane's two queries has its OWN reference here (the bf16 form shares
+// one: fp32's exponent range does not care, but a pair is precise only within 2^22 of fp16's top, and a query that inherits
+// the reference of a neighbour with larger scores would carry its whole row as fp16 subnormals -- measured: 4e-4 instead of
+// 8e-6); the reference enters each score chain as a freshly splat accumulator.  Plain control flow: this kernel's straight
+// (query group, block) order has no hand-placed slots to protect.
+template <int D, bool PVH = false>
 __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __bf16* __restrict__ ws, float* __restrict__ out,
-                                                                      float* __restrict__ lse2, int C, int L) {
+                                                                      float* __restrict__ lse2, int C, int L, float one) {
   static_assert(D == 16 || D == 32, "head dim");
+  static_assert(!PVH || D == 32, "the fp16-pair P.V form of this kernel is the d_head 32 one");
+  constexpr int NPC = PVH ? 2 : 3;             // pieces of V and of P
   constexpr int KS = D / 16;                   // k-steps of the QK^T product
   constexpr int NPV = (D == 16) ? 4 : 6;       // P.V MFMAs per 16 keys
   constexpr int KROWB = D * 2 + 16;            // bytes per key of one K piece in LDS (+16: conflict-free ds_read_b128)
@@ -125,13 +156,13 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
   constexpr int VROWB = KT * 2 + 8;            // bytes per d row of one V piece (+8: rows spread over the banks)
   constexpr int VPART = D * VROWB;
   constexpr int NKC = 3 * KT * D / 8;          // 16-byte chunks of a K tile (all pieces)
-  constexpr int NVC = 3 * D * 8;               // 16-byte chunks of a V tile
+  constexpr int NVC = NPC * D * 8;             // 16-byte chunks of a V tile
   constexpr int NLD = (NKC + NVC) / THREADS;   // chunks per thread: 3 (d 16), 6 (d 32)
   static_assert((NKC + NVC) % THREADS == 0, "staging geometry");
   constexpr int QB = 256;                      // queries per workgroup: 4 waves x 2 groups of 32
 
   constexpr int VBASE = 3 * KPART;                                         // one buffer = K pieces, V pieces, one row of zeros
-  constexpr int BUFB = (VBASE + 3 * VPART + VROWB + 15) / 16 * 16;
+  constexpr int BUFB = (VBASE + NPC * VPART + VROWB + 15) / 16 * 16;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][BUFB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -149,7 +180,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
   // zero row of both V buffers (read by the upper half of the one-piece V operands at d_head 16)
   if (tid < 2 * (VROWB / 4)) {
     const int bufi = tid / (VROWB / 4), w = tid - bufi * (VROWB / 4);
-    *reinterpret_cast<unsigned*>(&smem[bufi][VBASE + 3 * VPART + 4 * w]) = 0u;
+    *reinterpret_cast<unsigned*>(&smem[bufi][VBASE + NPC * VPART + 4 * w]) = 0u;
   }
 
   // Q operands (B of S^T = K Q^T): lane (query l31, half h) holds d = 16 ks + 8 h .. + 7 of each piece
@@ -204,7 +235,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
 
   // operand addresses inside a buffer
   const int kaddr = l31 * KROWB + 16 * h;                                  // + piece * KPART + key block * 32 * KROWB + ks * 32
-  constexpr int NVK = (D == 16) ? 2 : 3;                                   // V operand kinds (d_head 16) / pieces (d_head 32)
+  constexpr int NVK = (D == 16) ? 2 : NPC;                                 // V operand kinds (d_head 16) / pieces (d_head 32)
   int vaddr[NVK];
   if constexpr (D == 16) {
     const int d = l31 & 15;
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
     vaddr[1] = up ? 3 * VPART : 2 * VPART + d * VROWB + 8 * h;             // [v2; 0]
   } else {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) vaddr[p] = p * VPART + l31 * VROWB + 8 * h;
+    for (int p = 0; p < NPC; ++p) vaddr[p] = p * VPART + l31 * VROWB + 8 * h;
   }
 
   // negm16: the softmax reference point, negated and splat over an accumulator tuple = the C operand that starts every
@@ -222,6 +253,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
   // NaN output and the check pass (attention.hip) recomputes that query block.
   f32x16 O[2], negm16;
   f32x2 l_run[2];
+  float negm2[2] = {0.f, 0.f};          // PVH: -m of the lane's two queries
 #pragma unroll
   for (int G = 0; G < 2; ++G) {
     l_run[G] = f32x2{0.f, 0.f};
@@ -278,10 +310,54 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
     l_run[G][0] += sum0;
     l_run[G][1] += sum1;
   };
+  // PVH: P = exp2(S) of one (block, query group) as fp16 pairs + the lane's row sums; the reference moves when it must
+  auto exp_pairs = [&](const f32x16& S, u32x4 (&pop)[2][3], float& sum0, float& sum1) {
+    sum0 = 0.f; sum1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p0 = __builtin_amdgcn_exp2f(S[4 * j]), p1 = __builtin_amdgcn_exp2f(S[4 * j + 1]);
+      const float p2 = __builtin_amdgcn_exp2f(S[4 * j + 2]), p3 = __builtin_amdgcn_exp2f(S[4 * j + 3]);
+      sum0 += p0 + p2;
+      sum1 += p1 + p3;
+      unsigned a0, a1, c0, c1;
+      split2(p0, p1, one, a0, a1);
+      split2(p2, p3, one, c0, c1);
+      const int ab = j >> 1, o = (j & 1) * 2;
+      pop[ab][0][o] = a0; pop[ab][1][o] = a1;
+      pop[ab][0][o + 1] = c0; pop[ab][1][o + 1] = c1;
+    }
+  };
+  auto softmax_pairs = [&](f32x16& S, int G, u32x4 (&pop)[2][3]) {
+    float sum0, sum1;
+    exp_pairs(S, pop, sum0, sum1);
+    // any lane whose 16 values sum to 2^15 or more: some P of this block may not fit fp16 (they are >= 0)
+    if (__builtin_amdgcn_ballot_w64(sum0 + sum1 >= P_TRIP) != 0ull) {
+      float mx = fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3]));
+#pragma unroll
+      for (int j = 1; j < 4; ++j) mx = fmaxf(mx, fmaxf(fmaxf(S[4 * j], S[4 * j + 1]), fmaxf(S[4 * j + 2], S[4 * j + 3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                       // the two lanes that share the query
+      const float delta = (mx > P_SHIFT + 1.0f) ? __builtin_ceilf(mx - P_SHIFT) : 0.f;
+      const int e = -(int)delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[G][r] = __builtin_ldexpf(O[G][r], e);
+      l_run[G][0] = __builtin_ldexpf(l_run[G][0], e);
+      l_run[G][1] = __builtin_ldexpf(l_run[G][1], e);
+      negm2[G] -= delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] -= delta;
+      exp_pairs(S, pop, sum0, sum1);
+    }
+    l_run[G][0] += sum0;
+    l_run[G][1] += sum1;
+  };
   auto pv = [&](const u32x4 (&vop)[2][NVK], const u32x4 (&pop)[2][3], int G) {
 #pragma unroll
     for (int ab = 0; ab < 2; ++ab) {
-      if constexpr (D == 16) {
+      if constexpr (PVH) {                               // small terms first
+        O[G] = mfma32h(vop[ab][1], pop[ab][0], O[G]);    // v1 p0
+        O[G] = mfma32h(vop[ab][0], pop[ab][1], O[G]);    // v0 p1
+        O[G] = mfma32h(vop[ab][0], pop[ab][0], O[G]);    // v0 p0
+      } else if constexpr (D == 16) {
         O[G] = mfma32(vop[ab][0], pop[ab][2], O[G]);     // v0 p2 (and v1 p2: a term beyond the six, for free)   small terms first
         O[G] = mfma32(vop[ab][1], pop[ab][0], O[G]);     // v2 p0
         O[G] = mfma32(vop[ab][0], pop[ab][1], O[G]);     // v0 p1, v1 p1
@@ -306,6 +382,13 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
 #pragma unroll
     for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(s0[r], s1[r]));
     tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+    if constexpr (PVH) {                 // per query: the maximum over its own first block
+      float t0 = s0[0], t1 = s1[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) { t0 = fmaxf(t0, s0[r]); t1 = fmaxf(t1, s1[r]); }
+      negm2[0] = P_SHIFT - fmaxf(t0, __shfl_xor(t0, 32, 64));
+      negm2[1] = P_SHIFT - fmaxf(t1, __shfl_xor(t1, 32, 64));
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) negm16[r] = -tm;
   }
@@ -315,9 +398,16 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
     load_v(buf, kb, vop);
 #pragma unroll
     for (int G = 0; G < 2; ++G) {
-      const f32x16 S = qk(kop, G, negm16);
+      if constexpr (PVH) {
+        float nm = negm2[G];
+        asm volatile("" : "+v"(nm));               // a fresh splat per chain: one tuple of registers, not one per query
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm16[r] = nm;
+      }
+      f32x16 S = qk(kop, G, negm16);
       u32x4 pop[2][3];
-      softmax_split(S, G, pop);
+      if constexpr (PVH) softmax_pairs(S, G, pop);
+      else softmax_split(S, G, pop);
       pv(vop, pop, G);
     }
   };
@@ -344,7 +434,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
     const float inv = bad ? __builtin_nanf("") : 1.0f / lt;
     const int q = qblk0 + 32 * G + l31;
     if (lse2 != nullptr && h == 0)
-      lse2[((size_t)b * heads + head) * L + q] = bad ? __builtin_nanf("") : __builtin_amdgcn_logf(lt) - negm16[0];
+      lse2[((size_t)b * heads + head) * L + q] = bad ? __builtin_nanf("") : __builtin_amdgcn_logf(lt) - (PVH ? negm2[G] : negm16[0]);
     // accumulator register r holds row 8 (r / 4) + 4 h + (r % 4) of O^T for query l31
     if (D == 16) {
 #pragma unroll
@@ -352,6 +442,13 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           obase[(size_t)(8 * jj + 4 * h + i) * L + q] = (O[G][4 * jj + i] + O[G][4 * (jj + 2) + i]) * inv;
+    } else if constexpr (PVH) {
+      const float* vinv = reinterpret_cast<const float*>(qs + 8 * piece);      // 2^-s per channel of this head (launch_v_split_h2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = 8 * (r >> 2) + 4 * h + (r & 3);
+        obase[(size_t)d * L + q] = (O[G][r] * inv) * vinv[d];
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) obase[(size_t)(8 * (r >> 2) + 4 * h + (r & 3)) * L + q] = O[G][r] * inv;
@@ -397,11 +494,16 @@ bool launch_mha_fwd_x3p(const float* qkv, float* o, float* lse2, int B, int C, i
   if (D == 16) {
     hipLaunchKernelGGL((qkv_split3_kernel<16>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);
     if (!wide) return launch_mha_fwd_x3(qkv, ws, o, lse2, B, C, heads, L, qscale, stream);
-    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<16>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
+    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<16>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L, 1.0f);
+  } else if (wide && mha_fwd_h2_enabled()) {
+    // P.V on fp16 pairs: Q, K as bf16 triples, V as fp16 pairs with per-row powers of two (the V region of the same workspace)
+    launch_qk_split3(qkv, ws, B, C, heads, L, qscale, stream);
+    launch_v_split_h2(qkv, ws, B, C, heads, L, stream);
+    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<32, true>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L, 1.0f);
   } else {
     hipLaunchKernelGGL((qkv_split3_kernel<32>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);
     if (!wide) return launch_mha_fwd_x3(qkv, ws, o, lse2, B, C, heads, L, qscale, stream);
-    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<32>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L);
+    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<32>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L, 1.0f);
   }
   return true;
 }

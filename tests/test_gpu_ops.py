@@ -329,19 +329,25 @@ def _h2_case(name, d, L, g):
         qkv[:, 2 * Cc:] *= torch.exp(torch.randn(1, Cc, 1, generator=g) * 6) * torch.exp(torch.randn(1, Cc, L, generator=g) * 2)
     elif name == "tiny-v":        # a head whose V is denormal-small next to normal ones
         qkv[:, 2 * Cc:2 * Cc + d] *= 1e-30
+    elif name == "quiet-neighbour":   # every other block of 32 queries has scores 2^-20 ... 2^20 times its neighbours': queries that
+        blk = (torch.arange(L) // 32) % 2 == 0                      # share a lane (d_head 32) must not share a softmax reference
+        qkv[:, :Cc, blk] *= 6.0
+        qkv[:, :Cc, ~blk] *= 0.05
     return qkv
 
 
-@pytest.mark.parametrize("name", ["ramp", "peaked", "late-spikes", "wide-v", "tiny-v"])
-def test_flash_attention_fp16_pairs_moving_reference_and_ranges(name, bf16x3_mode):
-    """attention_h2.hip (d_head 16 with a workspace): P as two fp16 pieces needs a reference that MOVES (fp16 ends at 65504)
-    and V scaled per channel row.  Error against float64 in the class of the fp32-MFMA kernel's on the same inputs, and --
-    in a process that skips the check pass -- not a single NaN: the kernel handled every row itself instead of poisoning
-    it for the fp32 kernel behind it."""
+@pytest.mark.parametrize("d", [16, 32])
+@pytest.mark.parametrize("name", ["ramp", "peaked", "late-spikes", "wide-v", "tiny-v", "quiet-neighbour"])
+def test_flash_attention_fp16_pairs_moving_reference_and_ranges(name, d, bf16x3_mode):
+    """attention_h2.hip (d_head 16) / attention_x3p.hip PVH (d_head 32), with a workspace: P as two fp16 pieces needs a
+    reference that MOVES (fp16 ends at 65504), one per query, and V scaled per channel row.  Error against float64 in the class
+    of the fp32-MFMA kernel's on the same inputs, and -- in a process that skips the check pass -- not a single NaN: the
+    kernel handled every row itself instead of poisoning it for the fp32 kernel behind it."""
     lib = bf16x3_mode
-    d, L, heads = 16, 4096, 8
-    g = torch.Generator().manual_seed({"ramp": 1, "peaked": 2, "late-spikes": 3, "wide-v": 4, "tiny-v": 5}[name])
+    L, heads = 4096, 8
+    g = torch.Generator().manual_seed({"ramp": 1, "peaked": 2, "late-spikes": 3, "wide-v": 4, "tiny-v": 5, "quiet-neighbour": 6}[name])
     qkv = _h2_case(name, d, L, g)
+    assert not torch.equal(_flash(lib, qkv, heads, workspace=True)[0], _flash(lib, qkv, heads)[0]), "the workspace path did not run its own kernel"
     ref = attention_core_ref(qkv, heads).double()
     o_h2, _ = _flash(lib, qkv, heads, workspace=True)
     _capi.check(lib.hdiff_set_contraction_mode(0))
@@ -370,12 +376,13 @@ import torch, hdiff_amd
 from hdiff_amd import _capi
 import test_gpu_ops as T
 lib = hdiff_amd.lib(); hdiff_amd.set_contraction_mode("bf16x3")
-for i, name in enumerate(["ramp", "peaked", "late-spikes", "wide-v"]):
-    qkv = T._h2_case(name, 16, 4096, torch.Generator().manual_seed(i + 1))
-    o, lse = T._flash(lib, qkv, 8, want_lse=True, workspace=True)
-    assert torch.isfinite(o).all() and torch.isfinite(lse).all(), name
-    ref = T.attention_core_ref(qkv, 8)
-    assert ((o.cpu() - ref).abs().amax(dim=2) <= 3e-5 * ref.abs().amax(dim=2) + 1e-30).all(), name
+for d in (16, 32):
+    for i, name in enumerate(["ramp", "peaked", "late-spikes", "wide-v"]):
+        qkv = T._h2_case(name, d, 4096, torch.Generator().manual_seed(i + 1))
+        o, lse = T._flash(lib, qkv, 8, want_lse=True, workspace=True)
+        assert torch.isfinite(o).all() and torch.isfinite(lse).all(), (name, d)
+        ref = T.attention_core_ref(qkv, 8)
+        assert ((o.cpu() - ref).abs().amax(dim=2) <= 3e-5 * ref.abs().amax(dim=2) + 1e-30).all(), (name, d)
 print("H2_ROWS_OK")
 ''' % (root, os.path.join(root, "tests"))
     env = dict(os.environ, HDIFF_NO_CHECK_PASS="1")
