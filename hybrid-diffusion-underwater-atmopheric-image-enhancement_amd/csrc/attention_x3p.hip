@@ -143,7 +143,10 @@ __global__ __launch_bounds__(THREADS) void qkv_split3_kernel(const float* __rest
 // the reference of a neighbour with larger scores would carry its whole row as fp16 subnormals -- measured: 4e-4 instead of
 // 8e-6); the reference enters each score chain as a freshly splat accumulator.  Plain control flow: this kernel's straight
 // (query group, block) order has no hand-placed slots to protect.
-template <int D, bool PVH = false>
+// PIPE (PVH only): both query groups' score chains are issued before the first group's exp / split stream, so that a wave's own
+// matrix work (the second group's 12 MFMAs, then the first group's P.V) runs beside its vector work instead of only the other
+// wave's; the references of the two groups are independent (one per query), so the order is free.
+template <int D, bool PVH = false, bool PIPE = false>
 __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __bf16* __restrict__ ws, float* __restrict__ out,
                                                                       float* __restrict__ lse2, int C, int L, float one) {
   static_assert(D == 16 || D == 32, "head dim");
@@ -396,6 +399,24 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
     u32x4 kop[3][KS], vop[2][NVK];
     load_k(buf, kb, kop);
     load_v(buf, kb, vop);
+    if constexpr (PVH && PIPE) {
+      f32x16 S2[2];
+#pragma unroll
+      for (int G = 0; G < 2; ++G) {
+        float nm = negm2[G];
+        asm volatile("" : "+v"(nm));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm16[r] = nm;
+        S2[G] = qk(kop, G, negm16);
+      }
+#pragma unroll
+      for (int G = 0; G < 2; ++G) {
+        u32x4 pop[2][3];
+        softmax_pairs(S2[G], G, pop);
+        pv(vop, pop, G);
+      }
+      return;
+    }
 #pragma unroll
     for (int G = 0; G < 2; ++G) {
       if constexpr (PVH) {
@@ -499,7 +520,11 @@ bool launch_mha_fwd_x3p(const float* qkv, float* o, float* lse2, int B, int C, i
     // P.V on fp16 pairs: Q, K as bf16 triples, V as fp16 pairs with per-row powers of two (the V region of the same workspace)
     launch_qk_split3(qkv, ws, B, C, heads, L, qscale, stream);
     launch_v_split_h2(qkv, ws, B, C, heads, L, stream);
-    hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<32, true>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L, 1.0f);
+    static const char* pe = getenv("HDIFF_X3P_PIPE");       // dev knob (A/B): 0 = the straight (group, block) order (2.129 vs 2.092 ms at L = 16384, B = 2)
+    if (!(pe && atoi(pe) == 0))
+      hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<32, true, true>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L, 1.0f);
+    else
+      hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<32, true>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L, 1.0f);
   } else {
     hipLaunchKernelGGL((qkv_split3_kernel<32>), sgrid, dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, qscale);
     if (!wide) return launch_mha_fwd_x3(qkv, ws, o, lse2, B, C, heads, L, qscale, stream);
