@@ -349,11 +349,16 @@ def test_flash_attention_fp16_pairs_moving_reference_and_ranges(name, d, bf16x3_
     qkv = _h2_case(name, d, L, g)
     assert not torch.equal(_flash(lib, qkv, heads, workspace=True)[0], _flash(lib, qkv, heads)[0]), "the workspace path did not run its own kernel"
     ref = attention_core_ref(qkv, heads).double()
-    o_h2, _ = _flash(lib, qkv, heads, workspace=True)
+    o_h2, lse = _flash(lib, qkv, heads, want_lse=True, workspace=True)
     _capi.check(lib.hdiff_set_contraction_mode(0))
     o_f32, _ = _flash(lib, qkv, heads)
     _capi.check(lib.hdiff_set_contraction_mode(1))
     assert torch.isfinite(o_h2).all()
+    # the log-sum-exp the backward reads: log2(l) plus the reference the row ENDED with, however often it moved
+    Cc = heads * d
+    q, k, _ = [z.reshape(1, heads, d, L).transpose(2, 3).double() for z in qkv.split(Cc, dim=1)]
+    s2 = (q @ k.transpose(2, 3)) / math.sqrt(d) * math.log2(math.e)
+    close(lse, (torch.logsumexp(s2 * math.log(2.0), dim=-1) / math.log(2.0)).float(), rel=1e-5, abs_=1e-4, what=f"lse2 {name} d={d}")
     scale = ref.abs().amax(dim=2, keepdim=True).clamp_min(1e-300)          # per channel row: rows differ by 2^30 in "wide-v"
     rms = lambda t: ((t.double().cpu() - ref) / scale).pow(2).mean().sqrt().item()
     worst = lambda t: ((t.double().cpu() - ref) / scale).abs().max().item()
