@@ -576,6 +576,40 @@ def test_conv3x3_fp16_pairs_outside_the_stated_range_is_loud(bf16x3_mode):
     assert torch.isnan(out).any()
 
 
+def test_gn_act_scale_and_weight_pairs_through_the_c_abi():
+    """hdiff_gn_act_scale and hdiff_pack_conv_weight_h2 called straight through the C ABI: the staged range is the stated bound
+    (sqrt(n - 1) max|gamma| + max|beta|) times gain, as a power of two with a factor two to spare; the packed pieces add up to
+    w 2^t to 2^-22 of the largest weight, the tail holds 2^-t and 2^t, channel padding is zero."""
+    lib, s = _capi.lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(21)
+    for Cc, n, gain in ((128, 4 * 65536, 1.0), (384, 12 * 4096, 1.0 / 0.85), (64, 2 * 64, 1.0)):
+        gamma, beta = (torch.randn(Cc, generator=g) * 3).to(DEV), (torch.randn(Cc, generator=g) * 2).to(DEV)
+        out = torch.zeros(2, device=DEV)
+        _capi.check(lib.hdiff_gn_act_scale(gamma.data_ptr(), beta.data_ptr(), Cc, C.c_int64(n), C.c_float(gain), out.data_ptr(), s))
+        bound = ((math.sqrt(n - 1) * gamma.abs() + beta.abs()).max().item()) * gain
+        sc, inv = out.tolist()
+        assert sc * inv == 1.0 and math.log2(sc) == round(math.log2(sc))              # an exact power of two and its inverse
+        assert 2.0 ** 13 <= bound * sc * (1 + 1e-6) and bound * sc < 2.0 ** 14 * (1 + 1e-6), (bound, sc)
+    cout, cin, cpad = 96, 48, 128
+    w = torch.randn(cout, cin, 3, 3, generator=g) * torch.exp(torch.randn(cout, 1, 1, 1, generator=g) * 2)
+    dw = w.to(DEV)
+    words = C.c_int64(0)
+    _capi.check(lib.hdiff_pack_conv_weight_h2_words(cout, cin, cpad, C.byref(words)))
+    assert words.value == (cin // 16) * 9 * 2 * cpad * 8 + 4
+    wp = torch.empty(words.value, dtype=torch.int32, device=DEV)
+    _capi.check(lib.hdiff_pack_conv_weight_h2(dw.data_ptr(), wp.data_ptr(), cout, cin, cpad, s))
+    torch.cuda.synchronize()
+    tail = wp[-4:].view(torch.float32).tolist()
+    inv_t, t = tail[1], tail[2]
+    assert inv_t * t == 1.0 and 2.0 ** 14 <= w.abs().max().item() * t < 2.0 ** 15
+    body = wp[:-4].view(torch.float16).float().reshape(cin // 16, 9, 2, cpad, 16).cpu()       # [chunk][tap][piece][co][16 ci]
+    back = (body[:, :, 0] + body[:, :, 1]) * inv_t                                             # [chunk][tap][co][16 ci]
+    want = w.reshape(cout, cin // 16, 16, 9).permute(1, 3, 0, 2)                               # [chunk][tap][co][16 ci]
+    assert (back[:, :, :cout] - want).abs().max().item() <= 2.0 ** -22 * w.abs().max().item()
+    assert (back[:, :, :cout] - want).abs().div(want.abs().clamp_min(2.0 ** -17 * w.abs().max().item())).max().item() <= 2.0 ** -22
+    assert body[:, :, :, cout:].abs().max().item() == 0.0
+
+
 def test_linear_rows_and_gather():
     g = torch.Generator().manual_seed(1)
     table = torch.randn(20, 128, generator=g)
