@@ -55,7 +55,10 @@ def _run_conv(x0, x1, sources, taps: E.TapSet, cout: int, cin: int, bias, out, *
     for (w, mode, ky, kx, acc) in sources:
         pk.add_source(w, mode, ky, kx, acc)
     if x3 is not None and in_stride == 1 and out_map == (1, 0, 1, 0):
-        pk.enable_x3(x3[0], transposed=x3[1])
+        if len(taps.dy) == 1:
+            pk.enable_x3_taps(x3[0], 1 if x3[1] else 0)      # 1x1: one tap on bf16 triples (conv1x1_x3.hip); transposed = the [in][out] reading
+        else:
+            pk.enable_x3(x3[0], transposed=x3[1])
     plan.packs.append(pk)
     plan.conv(x0, x1, pk, bias, out, B=B, H=H, W=W, VH=VH, VW=VW, in_stride=in_stride, out_map=out_map, gn=gn,
               addvec=addvec, residual=residual, act_range=act_range)
@@ -165,7 +168,7 @@ class _FusedConv(Function):
         taps = E.conv_taps(k, pad)
         out = torch.empty(B, cout, H, W, device=dev)
         _run_conv(conv_in0, conv_in1, [(weight, 0, taps.ky, taps.kx, 0)], taps, cout, cin, bias, out, B=B, H=H, W=W, VH=H,
-                  VW=W, gn=conv_gn, addvec=addvec, residual=residual, x3=(weight, False) if k == 3 else None,
+                  VW=W, gn=conv_gn, addvec=addvec, residual=residual, x3=(weight, False) if k in (1, 3) else None,
                   act_range=act_range if k == 3 else None)
         ctx.k, ctx.has_x1, ctx.has_gn, ctx.dropped = k, x1 is not None, gn_w is not None, mask is not None
         ctx.has_bias, ctx.has_vec, ctx.has_res = bias is not None, addvec is not None, residual is not None
@@ -210,7 +213,7 @@ class _FusedConv(Function):
             dtaps = E.TapSet(taps.dy, taps.dx, [pad - dy for dy in taps.dy], [pad - dx for dx in taps.dx])
             dA = torch.empty(B, cin, H, W, device=dev)
             _run_conv(dout, None, [(weight, 1, dtaps.ky, dtaps.kx, 0)], dtaps, cin, cout, None, dA, B=B, H=H, W=W, VH=H, VW=W,
-                      x3=(weight, True) if k == 3 else None)
+                      x3=(weight, True) if k in (1, 3) else None)
             if ctx.dropped:
                 _capi.check(lib.hdiff_mul(dA.data_ptr(), mask.data_ptr(), dA.data_ptr(), dA.numel(), s), "mul")
             if ctx.has_gn:

@@ -100,11 +100,26 @@ struct ConvX3K {
 };
 void launch_conv3x3_x3(const ConvX3K& k, int B, hipStream_t stream);
 
+// conv1x1_x3.hip: the 1x1 / stride-1 convolution on bf16 triples (no LDS; operands split in registers)
+struct Conv1x1X3K {
+  const float* x0;
+  const float* x1;
+  int C0, Cin;
+  long HW;
+  const unsigned* wp3;             // [Cin/16][1][3][CoutPad][8] packed bf16 pairs (hdiff_pack_conv_weight_x3_taps, one tap)
+  int CoutPad, Cout;
+  const float* bias;
+  const float* addvec;
+  const float* residual;
+  float* out;
+};
+void launch_conv1x1_x3(const Conv1x1X3K& k, int B, hipStream_t stream);
+
 int contraction_mode();   // HDIFF_CONTRACT_*
 
 // Mutation switch of the parity suite's own sensitivity test (tests/test_gpu_mutation.py): a library built with
 // -DHDIFF_MUTANT=<mask> silently drops ONE lowest-order piece product (bf16 pieces 0 x 2: 2^-16 of the product) --
-// bit 0 in the split-bf16 3x3 convolution (its fp16-pair form: the low five bits of every activation's second piece), bit 1 in the
+// bit 0 in the split-bf16 3x3 and 1x1 convolutions (the 3x3's fp16-pair form: the low five bits of every activation's second piece), bit 1 in the
 // d_head 32 attention forward (attention_x3p.hip), bit 2 in the
 // score product of the d_head 16 attention forward (attention_h2.hip).  The tightened model-level tests must FAIL on it.
 #ifndef HDIFF_MUTANT

@@ -603,7 +603,7 @@ int configure(const hdiff_conv_desc* d, ConvCfg& c) {
 
 }  // namespace
 
-namespace { bool is_direct_1x1(const hdiff_conv_desc* d); bool is_x3_conv(const hdiff_conv_desc* d); }
+namespace { bool is_direct_1x1(const hdiff_conv_desc* d); bool is_x3_conv(const hdiff_conv_desc* d); bool is_x3_1x1(const hdiff_conv_desc* d); }
 
 extern "C" int hdiff_conv2d_fwd_workspace(const hdiff_conv_desc* d, int64_t* floats_out) {
   HDIFF_CHECK_ARG(floats_out, "conv2d_fwd_workspace: null pointer");
@@ -680,6 +680,15 @@ bool is_direct_1x1(const hdiff_conv_desc* d) {
          d->OH == d->H && d->OW == d->W && (long)d->B * d->H * d->W >= 32768 && ((long)d->H * d->W) % 128 == 0 &&
          d->C0 % 2 == 0 && (long)(d->C0 + d->C1) * d->H * d->W < (1L << 30) && d->CinPad * d->CoutPad < (1 << 30);
 }
+// ... and in the split-bf16 mode, with a one-tap bf16-triple pack (hdiff_pack_conv_weight_x3_taps, ntaps = 1) and 16-channel-aligned
+// inputs, the same GEMM runs on the bf16 MFMA (conv1x1_x3.hip).  Dev knob HDIFF_CONV1X1=f32 keeps the fp32-input kernel.
+bool is_x3_1x1(const hdiff_conv_desc* d) {
+  static const char* e = getenv("HDIFF_CONV1X1");
+  if (e && strcmp(e, "f32") == 0) return false;
+  const int Cin = d->C0 + d->C1;
+  return d->wp_x3 != nullptr && hdiff::contraction_mode() == HDIFF_CONTRACT_BF16X3 && Cin % 16 == 0 &&
+         (d->C1 == 0 || d->C0 % 16 == 0) && ((long)d->H * d->W) % 256 == 0 && d->CoutPad % 64 == 0;
+}
 }  // namespace
 
 extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream) {
@@ -707,6 +716,14 @@ extern "C" int hdiff_conv2d_fwd(const hdiff_conv_desc* d, hdiff_stream_t stream)
     (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
     hdiff::launch_conv3x3_x3(q, d->B, (hipStream_t)stream);
     HDIFF_CHECK_LAUNCH("conv3x3_x3_kernel");
+    return HDIFF_OK;
+  }
+  if (is_direct_1x1(d) && is_x3_1x1(d)) {          // bf16x3 mode: the same GEMM on bf16 triples (conv1x1_x3.hip)
+    hdiff::Conv1x1X3K q{d->x0, d->x1, d->C0, d->C0 + d->C1, (long)d->H * d->W, (const unsigned*)d->wp_x3, d->CoutPad, d->Cout,
+                        d->bias, d->addvec, d->residual, d->out};
+    (void)hipGetLastError();  // drop any stale error left by another HIP user in this thread
+    hdiff::launch_conv1x1_x3(q, d->B, (hipStream_t)stream);
+    HDIFF_CHECK_LAUNCH("conv1x1_x3_kernel");
     return HDIFF_OK;
   }
   if (is_direct_1x1(d)) {

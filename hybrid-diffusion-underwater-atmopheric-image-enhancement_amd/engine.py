@@ -126,7 +126,7 @@ class PackedConv:
     def enable_x3_taps(self, w: torch.Tensor, mode: int) -> None:
         """The split-bf16 copy for a launch whose taps are a subset of the 3x3 neighbourhood reading elements (ky, kx) of a
         larger kernel: the output-parity phases of ConvTranspose2d(5, stride 2) (mode 1 = its [Cin][Cout][5][5] layout)."""
-        if self.ntaps in (4, 6, 9) and self.cin % 16 == 0 and all(-1 <= v <= 1 for v in self.taps.dy + self.taps.dx):
+        if self.ntaps in (1, 4, 6, 9) and self.cin % 16 == 0 and all(-1 <= v <= 1 for v in self.taps.dy + self.taps.dx):
             self.wp3 = torch.empty((self.cin // 16) * self.ntaps * 3 * self.cout_pad * 8, dtype=torch.int32, device=self.wp.device)
             self._x3_src = w
             self._x3_taps = (int(mode), int(w.shape[2]), int(w.shape[3]))
@@ -402,6 +402,8 @@ def _std_pack(plan: Plan, w: torch.Tensor, k: int, pad: int) -> PackedConv:
     pk.add_source(w, 0, taps.ky, taps.kx, 0)
     if k == 3 and pad == 1:
         pk.enable_x3(w)
+    elif k == 1 and pad == 0:
+        pk.enable_x3_taps(w, 0)          # one tap: the 1x1 GEMM on bf16 triples (conv1x1_x3.hip) in the bf16x3 mode
     return pk
 
 

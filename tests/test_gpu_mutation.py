@@ -25,11 +25,12 @@ def test_a_dropped_low_order_piece_product_turns_the_error_class_tests_red():
     import hdiff_amd
     from hdiff_amd import _capi
     mutant = _capi.MUTANT_PATH
-    src = [os.path.join(_capi.CSRC, f) for f in ("conv3x3_x3.hip", "attention_x3p.hip", "attention_h2.hip", "common.h")]
+    src = [os.path.join(_capi.CSRC, f) for f in ("conv3x3_x3.hip", "conv1x1_x3.hip", "attention_x3p.hip", "attention_h2.hip", "common.h")]
     if not os.path.isfile(mutant) or os.path.getmtime(mutant) < max(os.path.getmtime(f) for f in src):
         mutant = _capi.build_mutant()
     targets = ["tests/test_gpu_ops.py::test_conv3x3_split_bf16_is_fp32_class",
                "tests/test_gpu_ops.py::test_conv3x3_fp16_pairs_is_fp32_class",
+               "tests/test_gpu_ops.py::test_conv1x1_split_bf16_is_fp32_class",
                "tests/test_gpu_ops.py::test_flash_attention_split_bf16_is_fp32_class"]
     env = dict(os.environ, HDIFF_LIB=mutant)
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-rf", "-p", "no:cacheprovider"] + targets, cwd=ROOT, env=env,
@@ -40,6 +41,8 @@ def test_a_dropped_low_order_piece_product_turns_the_error_class_tests_red():
     conv = [l for l in failed if "test_conv3x3_split_bf16_is_fp32_class" in l]
     att_pre = [l for l in failed if "test_flash_attention_split_bf16_is_fp32_class" in l and "pre-split" in l]
     assert len(conv) == 4, (conv, out[-2000:])                               # every convolution shape
+    one = [l for l in failed if "test_conv1x1_split_bf16_is_fp32_class" in l]
+    assert len(one) == 4, (one, out[-2000:])                                 # ... and of the 1x1 kernel
     pairs = [l for l in failed if "test_conv3x3_fp16_pairs_is_fp32_class" in l]
     assert len(pairs) == 4, (pairs, out[-2000:])                             # ... of the fp16-pair form too (2^-16 of every activation masked)
     assert any("16-" in l for l in att_pre) and any("32-" in l for l in att_pre), (att_pre, out[-2000:])   # both head widths

@@ -84,6 +84,34 @@ def test_conv1x1_direct_gemm_path(C0, C1, cout):
     close(run_conv(x0, x1, w, None, 1, 0), F.conv2d(xin.double(), w.double()).float(), rel=1e-5, what="conv1x1 direct, no epilogue")
 
 
+@pytest.mark.parametrize("C0,C1,cout,S,B", [(128, 0, 384, 128, 2), (128, 128, 40, 128, 2), (256, 0, 256, 64, 8), (64, 48, 128, 128, 2)])
+def test_conv1x1_split_bf16_is_fp32_class(C0, C1, cout, S, B, bf16x3_mode):
+    """conv1x1_x3.hip: the full-resolution 1x1 convs (attention projections, shortcuts) on bf16 triples in the bf16x3 mode --
+    operands split in registers, no LDS.  Error against float64 in the class of the fp32-MFMA kernel's (conv1x1_direct.hip);
+    concat input with the seam on a 16-channel boundary, a channel tail (cout 40), bias + vector + residual epilogue."""
+    lib = bf16x3_mode
+    g = torch.Generator().manual_seed(C0 + 3 * C1 + cout)
+    cin = C0 + C1
+    x0 = torch.randn(B, C0, S, S, generator=g) * torch.exp(torch.randn(1, C0, 1, 1, generator=g))
+    x1 = torch.randn(B, C1, S, S, generator=g) if C1 else None
+    w = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+    b, vec, res = torch.randn(cout, generator=g), torch.randn(B, cout, generator=g), torch.randn(B, cout, S, S, generator=g)
+    xin = (x0 if x1 is None else torch.cat([x0, x1], dim=1)).double()
+    want = F.conv2d(xin, w.double(), b.double()) + vec.double()[:, :, None, None] + res.double()
+    got_x3 = run_conv(x0, x1, w, b, 1, 0, addvec=vec, residual=res)
+    _capi.check(lib.hdiff_set_contraction_mode(0))
+    got_f32 = run_conv(x0, x1, w, b, 1, 0, addvec=vec, residual=res)
+    _capi.check(lib.hdiff_set_contraction_mode(1))
+    assert not torch.equal(got_x3, got_f32), "the split-bf16 1x1 kernel did not run"
+    close(got_x3, want.float(), rel=1e-5, what="conv1x1 split-bf16")
+    rms = lambda t: (t.double().cpu() - want).pow(2).mean().sqrt().item()
+    worst = lambda t: (t.double().cpu() - want).abs().max().item()
+    print(f"conv1x1 {cin}->{cout} at {S}: rms vs float64: triples {rms(got_x3):.3e}, fp32-MFMA {rms(got_f32):.3e}")
+    assert rms(got_x3) <= 1.5 * rms(got_f32) + 1e-12, (rms(got_x3), rms(got_f32))
+    assert worst(got_x3) <= 2.0 * worst(got_f32) + 1e-12, (worst(got_x3), worst(got_f32))
+    close(run_conv(x0, x1, w, None, 1, 0), F.conv2d(xin, w.double()).float(), rel=1e-5, what="conv1x1 split-bf16, no epilogue")
+
+
 def test_conv_fused_prologue_epilogue_concat():
     g = torch.Generator().manual_seed(9)
     B, C0, C1, Cout, H, W = 2, 64, 32, 64, 16, 16
