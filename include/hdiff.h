@@ -122,7 +122,8 @@ typedef struct hdiff_conv_desc {
   int64_t splitk_floats;
   /* optional (ABI 2): the same weights as three bf16 pieces (hdiff_pack_conv_weight_x3).  Used instead of wp when the
    * contraction mode is HDIFF_CONTRACT_BF16X3 and the launch is a stride-1 conv with Cin % 16 == 0 whose taps lie in the 3x3
-   * neighbourhood (the plain 3x3 / pad-1 conv; a transposed-conv phase with its (2, py, 2, px) output map);
+   * neighbourhood (the plain 3x3 / pad-1 conv; a transposed-conv phase with its (2, py, 2, px) output map), or (ABI 5) a
+   * full-resolution 1x1 / stride-1 conv with a ONE-tap pack from hdiff_pack_conv_weight_x3_taps (Cin % 16 == 0, H * W % 256 == 0);
    * NULL = always the fp32-input MFMA.  Tap order: hdiff_pack_conv_weight_x3 stores tap t = (t / 3, t % 3), so a plain 3x3
    * launch must list tap_dy[t] = t / 3 - 1, tap_dx[t] = t % 3 - 1 (any other order of the nine taps, and any list with a
    * repeated tap, runs the fp32 kernel on wp instead); a pack made by hdiff_pack_conv_weight_x3_taps holds the taps in
