@@ -60,8 +60,14 @@ __device__ constexpr int TERM_X[6] = {0, 1, 2, 0, 1, 0};
 // load of X per channel serves both tiles), M tile mt = channels co0 + 32 mt + l; a workgroup = 4 waves = 256 consecutive pixels.
 // Preconditions (checked by the dispatcher in conv_igemm.hip): HW % 256 == 0, Cin % 16 == 0, C0 % 16 == 0 (a 16-channel step
 // never straddles the concat seam: the activation base pointer is wave-uniform), CoutPad % 64 == 0.
+// WLDS: the chunk's weight pieces (6 KB per workgroup) are staged ONCE per workgroup in LDS and every wave reads its A operands
+// from there, instead of every wave fetching its own 6 KB from L2 -- the 48 KB of a channel block's weights do not fit the 32 KB
+// vector L1, so without this the four waves of a workgroup quadruple the L2 -> L1 traffic of the weights (one LDS-only barrier per
+// chunk).  Measured +4 ... +8 % (1.237 -> 1.186 ms for 128 -> 384 at 256^2, batch 16; 0.994 -> 0.915 for 384 -> 128): the default.
+template <bool WLDS>
 __global__ __launch_bounds__(THREADS, 3) void conv1x1_x3_kernel(const Conv1x1X3K p) {
   constexpr int MT = 2, WN = 2;
+  __shared__ __attribute__((aligned(16))) u32x4 sW[WLDS ? 2 : 1][WLDS ? 3 * 64 * 2 : 1];      // [buffer][piece][channel][half]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   // Workgroup -> (pixel tile, channel block): the channel blocks of one pixel tile read the same X rows.  Workgroups go to the 8
@@ -138,17 +144,64 @@ __global__ __launch_bounds__(THREADS, 3) void conv1x1_x3_kernel(const Conv1x1X3K
     }
   };
 
+  if constexpr (WLDS) {
+    // staging: 384 units of 16 bytes per chunk; unit u = (piece, channel, half); thread tid takes u = tid and u = 256 + tid (< 384)
+    const unsigned* wsrc[2];
+    int wdst[2];
 #pragma unroll
-  for (int i = 0; i < XD; ++i) load_x(xr[i], i);
-  load_w(wr[0], 0);
-  // the ring indices must be compile-time constants (register arrays): XD + 1 = 4 chunks per trip, weights alternate
-  for (int c = 0; c < nchunks; c += XD + 1) {
+    for (int i = 0; i < 2; ++i) {
+      int u = i * THREADS + tid;
+      if (u >= 384) u -= 128;                       // the spare half round repeats units 256 .. 383 (same bytes to the same place)
+      const int pc = u >> 7, rem = u & 127;
+      wsrc[i] = p.wp3 + (size_t)pc * w_piece + (size_t)(co0 + (rem >> 1)) * 8 + (rem & 1) * 4;
+      wdst[i] = u;
+    }
+    u32x4 wst[2];
+    auto wload = [&](int c) {
+      const size_t off = (size_t)min(c, nchunks - 1) * w_chunk;
 #pragma unroll
-    for (int i = 0; i < XD + 1; ++i) {
-      if (c + i < nchunks) {                         // uniform
-        if (!(C1X3_ABL & 1)) load_x(xr[(i + XD) % (XD + 1)], c + i + XD);
-        if (!(C1X3_ABL & 2)) load_w(wr[(i + 1) & 1], c + i + 1);
-        mma(xr[i], wr[i & 1]);
+      for (int i = 0; i < 2; ++i) wst[i] = *reinterpret_cast<const u32x4*>(wsrc[i] + off);
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) sW[buf][wdst[i]] = wst[i];
+    };
+    auto wread = [&](u32x4 (&w)[MT][3], int buf) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) w[mt][pc] = sW[buf][(pc * 64 + 32 * mt + l31) * 2 + h];
+    };
+    wload(0);
+    load_x(xr[0], 0);
+    wstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (c + i < nchunks) {                       // uniform
+          wload(c + i + 1);
+          load_x(xr[(i + 1) & 1], c + i + 1);
+          wread(wr[0], i);
+          mma(xr[i], wr[0]);
+          wstore((i + 1) & 1);                       // buffer (i + 1) & 1 was last read one chunk ago, before the previous barrier
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // orders LDS only: the X loads of the next chunk stay in flight
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < XD; ++i) load_x(xr[i], i);
+    load_w(wr[0], 0);
+    // the ring indices must be compile-time constants (register arrays): XD + 1 chunks per trip, weights alternate
+    for (int c = 0; c < nchunks; c += XD + 1) {
+#pragma unroll
+      for (int i = 0; i < XD + 1; ++i) {
+        if (c + i < nchunks) {                         // uniform
+          if (!(C1X3_ABL & 1)) load_x(xr[(i + XD) % (XD + 1)], c + i + XD);
+          if (!(C1X3_ABL & 2)) load_w(wr[(i + 1) & 1], c + i + 1);
+          mma(xr[i], wr[i & 1]);
+        }
       }
     }
   }
@@ -206,7 +259,9 @@ namespace hdiff {
 
 void launch_conv1x1_x3(const Conv1x1X3K& k, int B, hipStream_t stream) {
   dim3 grid(cdiv(k.Cout, 64), (unsigned)(k.HW / 256), B);
-  hipLaunchKernelGGL(conv1x1_x3_kernel, grid, dim3(THREADS), 0, stream, k);
+  static const char* e = getenv("HDIFF_CONV1X1_WLDS");        // dev knob (A/B): 0 = every wave fetches its own weight operands from L2
+  if (e && atoi(e) == 0) hipLaunchKernelGGL(conv1x1_x3_kernel<false>, grid, dim3(THREADS), 0, stream, k);
+  else hipLaunchKernelGGL(conv1x1_x3_kernel<true>, grid, dim3(THREADS), 0, stream, k);
 }
 
 }  // namespace hdiff
