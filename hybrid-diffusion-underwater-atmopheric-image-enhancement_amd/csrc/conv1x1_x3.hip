@@ -10,11 +10,11 @@
 //
 // Why its own kernel (round 3 routed the 1x1 convs through the 3x3 kernel's centre tap and measured them SLOWER than the fp32
 // kernel, 61-84 against 76-86 TFLOP/s): there one tap gives the staging split nothing to hide behind -- a workgroup split a
-// 10 x 34 patch through LDS for 64 channels and one tap.  Here, as in conv1x1_direct.hip, nothing goes through LDS and there are
-// no barriers: a lane loads the 8 input channels of its two pixels straight from the NCHW rows (8-byte loads, coalesced over
-// the lanes), splits them in registers (5.5 vector instructions per value) into the B operands of its two pixel tiles, and each
-// split value feeds 64 output channels x 6 products; the weights arrive pre-split from hdiff_pack_conv_weight_x3_taps (one tap)
-// as 16-byte A operands out of L1 / L2.  Per 16-channel step and wave: 24 MFMAs (768 matrix cycles) beside ~120 vector
+// 10 x 34 patch through LDS for 64 channels and one tap.  Here, as in conv1x1_direct.hip, the activations do not go through LDS:
+// a lane loads the 8 input channels of its two pixels straight from the NCHW rows (8-byte loads, coalesced over the lanes),
+// splits them in registers (5.5 vector instructions per value) into the B operands of its two pixel tiles, and each split value
+// feeds 64 output channels x 6 products; the weights arrive pre-split from hdiff_pack_conv_weight_x3_taps (one tap) and are
+// staged once per workgroup and chunk in LDS (WLDS below), from where every wave reads its 16-byte A operands.  Per 16-channel step and wave: 24 MFMAs (768 matrix cycles) beside ~120 vector
 // instructions; the fp32 kernel spends 2048 matrix cycles on the same step.  Measured: 84-86 TFLOP/s-eq for 128 -> 384 at 256^2,
 // batch 16 (fp32 kernel 79-81), 108-112 for 256 -> 768 at 128^2 and 384 -> 128 at 256^2 (84-90), error against float64 0.88x the
 // fp32 kernel's -- a modest step, not the 150 the matrix time alone would allow: see the ablation note in the loop.
