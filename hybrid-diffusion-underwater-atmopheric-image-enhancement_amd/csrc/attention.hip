@@ -568,7 +568,8 @@ int launch_d(const float* qkv, float* o, float* lse2, int B, int C, int heads, i
     // d_head 32 on the fixed-reference kernel: 134 TFLOP/s against 120 on the running-max kernel (L = 16 384, batch 16)
     if (att_nq_override() > 0) nq = att_nq_override();
     if (nq == 4 && contraction_mode() == HDIFF_CONTRACT_BF16X3 &&
-        (launch_mha_fwd_h2(qkv, o, lse2, B, C, heads, L, qscale, ws, ws_bytes, stream) ||       // P.V on fp16 pairs (needs the workspace)
+        (launch_mha_fwd_h2w(qkv, o, lse2, B, C, heads, L, qscale, ws, ws_bytes, stream) ||      // d_head 16 on 32x32x16 tiles (needs the workspace)
+         launch_mha_fwd_h2(qkv, o, lse2, B, C, heads, L, qscale, ws, ws_bytes, stream) ||       // P.V on fp16 pairs (needs the workspace)
          launch_mha_fwd_x3p(qkv, o, lse2, B, C, heads, L, qscale, ws, ws_bytes, stream) ||      // pre-split operands (needs the workspace)
          launch_mha_fwd_x3(qkv, nullptr, o, lse2, B, C, heads, L, qscale, stream))) {
       // split-bf16 kernel (attention_x3.hip), same fixed-reference protocol: overflow-proof fp32 kernel in check mode behind it

@@ -45,6 +45,9 @@ namespace {
 #ifndef H2_ABL
 #define H2_ABL 0      // timing ablations (wrong results by construction; tools/README.md): 1 no workgroup barrier, 2 no rolling
 #endif                // K / Q reloads, 4 no global -> LDS staging in the loop, 8 no reference check, 16 no V reload
+#ifndef H2_DIAG
+#define H2_DIAG 0       // diagnostic build: s_memtime / s_memrealtime around the tile loop (tools/h2w_clock.py); never set in the product
+#endif
 #ifndef H2_VALU_PER_STAGE
 #define H2_VALU_PER_STAGE 54
 #endif
@@ -513,6 +516,9 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
     stage_fn(std::integral_constant<int, 3>{}, first_tag, std::true_type{});
   };
 
+#if H2_DIAG
+  const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   stage_load(0);
   stage_store(0);
   __syncthreads();
@@ -525,6 +531,13 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
 #pragma unroll
   for (int n = 0; n < NPV; ++n) pv_mfma(NQ - 1, 1, n);
 
+#if H2_DIAG
+  if (tid == 0) {
+    unsigned long long* dg = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(const_cast<__bf16*>(wsq + 8 * piece_n)) + 64) + 2 * tile.x;
+    dg[0] = __builtin_amdgcn_s_memtime() - diag_t0;
+    dg[1] = __builtin_amdgcn_s_memrealtime() - diag_r0;
+  }
+#endif
   float* obase = out + ((size_t)b * C + (size_t)head * D) * L;
   const float* vinv = reinterpret_cast<const float*>(wsq + 8 * piece_n);      // 2^-s per channel of this head
 #pragma unroll
