@@ -11,8 +11,19 @@
 // (the compiler emits exactly these from the plain C below when its SLP vectoriser is off -- with it the residuals become a
 // v_pk_fma_f32, which stalls against the MFMA stream; all three issue like v_perm / v_and beside the MFMA, h2_probe part B).
 //
-//   S  = Q K^T : unchanged -- bf16 triples, six products along the MFMA's 32 contraction slots (3 MFMAs per 16x16 tile
-//                at d_head 16), chain started from -m.  An error in S is an error in the exponent: it stays at fp32 class.
+//   S  = Q K^T : round 5 -- fp16 pairs with a balance PER TERM, four products on TWO MFMAs per 16x16 tile (bf16 triples: six on
+//                three).  Round 4 had rejected pairs for the scores: S is an exponent, it must come out unscaled, and one scale
+//                pair q 2^a, k 2^-a cannot keep both SECOND pieces above fp16's 2^-3 full-precision floor.  But every product
+//                term is its own set of contraction slots and carries its own balance:
+//                    k = k0 + k1, q = q0 + q1 (fp16 roundings of k 2^a, q 2^-a; a per (sample, head) from the maxima)
+//                    S = k0 q0 + (k0 2^-8)(q1 2^8)  |  (k1 2^8)(q0 2^-8) + k1 q1
+//                the second pieces are stored scaled UP by 2^8 (normal numbers whenever the value is), their partners scaled
+//                DOWN, where fp16's absolute floor 2^-25 meets a factor 2^-3 |x| -- harmless, and only the ABSOLUTE error of an
+//                exponent matters.  tools/h2_sim_qk_terms.py: error of S against float64 1.02x the fp32 chain's (Gaussian,
+//                peaked, spiked, ramped keys, |q| 2^-10 / |k| 2^10, channels nine binades apart); three products: 1.14x.
+//                The chain starts from -m and adds the large MFMA first.  Why it pays although this kernel is bound by vector
+//                issue: it is ALSO at the board's power limit (profiles/r05_attention_h2w_32x32.txt) -- a third fewer score
+//                products are joules, 32 cycles less held issue per stage, and 16 registers of Q operands.
 //   O += P V   : P = h0 + h1 with |P - h0 - h1| <= 2^-23 P (one fp32 ulp: the second piece keeps 11 of the residual's 12
 //                bits) or <= 2^-25 absolute (fp16 subnormal spacing 2^-24); V likewise as two fp16 pieces of V * 2^s with
 //                the power of two s chosen PER CHANNEL ROW so that max |V 2^s| lies in [2^14, 2^15) (v_split_h2_kernel; O is
@@ -58,15 +69,11 @@ constexpr float P_SHIFT = 8.0f;                   // the reference point enters 
 constexpr float P_TRIP = 32768.0f;                // per-lane sum of one stage's 16 P values that moves the reference
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -196,12 +203,89 @@ __device__ __forceinline__ void h2_rare_exp_split(unsigned long long cond, float
                : "scc");
 }
 
-// split-product terms of Q K^T (piece of K, piece of Q): all i + j <= 2.  At d_head 16 two terms share one MFMA (the low
-// and the high half of its 32 contraction slots); they are paired so that MFMA 0 and MFMA 1 take the SAME K operand
-// (k0 | k1) -- against (q0 | q1) and (q1 | q0) -- and MFMA 2 takes (k0 | k2) against (q2 | q0): two K operand sets per 16
-// keys instead of three (16 registers and a third of the K reads from LDS), which is what lets Q stay in registers.
-__device__ constexpr int TERM_A[6] = {0, 1, 0, 1, 0, 2};
-__device__ constexpr int TERM_B[6] = {0, 1, 1, 0, 2, 0};
+// Score operands.  K pieces in the workspace / LDS: 0 = k0, 1 = k0 2^-8, 2 = k1 2^8, 3 = k1; Q pieces in registers: q0, q1 2^8 read
+// from the workspace, q0 2^-8 and q1 made from them.  MFMA j contracts K operand set j (pieces 2 j | 2 j + 1 on the low | high 16
+// slots) with Q operand set j: MFMA 0 = k0 q0 + (k0 2^-8)(q1 2^8), MFMA 1 = (k1 2^8)(q0 2^-8) + k1 q1.
+constexpr int QK_SHIFT = 8;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Q and K of qkv [B][3C][L] (fp32) -> fp16 score operands (see QK_SHIFT) in the workspace, per (sample, head):
+//   piece 0: q0 [L][D], 1: q1 2^8 [L][D], 2..5: k0, k0 2^-8, k1 2^8, k1 [L][D]   (q = q_in qscale 2^-a, k = k_in 2^a)
+// Pass 1 (qk_rowmax_kernel, grid (2C, B)): max |x| of every Q / K channel row into rowmax[B][2C] behind the pairs.
+// Pass 2 (qk_split_h2_kernel, grid (L / 256, 2 heads, B)): thread = one position, all D channels; the balance a puts the two
+// maxima of the head in the same binade (both then sit ~2^1..2^4 for O(1) scores: 2^11 below fp16's top, 2^15 above its
+// normal floor); clamped so that every power of two stays a normal float.  An infinite or NaN input stays one (the row's
+// output is then NaN and the caller's check pass takes the query block, as for every kernel of this family).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void qk_rowmax_kernel(const float* __restrict__ qkv, float* __restrict__ rowmax, int C, int L) {
+  const int row = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* src = qkv + ((size_t)b * 3 * C + row) * L;
+  __shared__ float red[THREADS / 64];
+  float amax = 0.f;
+  for (int i = tid; i < L / 4; i += THREADS) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * (size_t)i);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  if (tid == 0) rowmax[(size_t)b * 2 * C + row] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+template <int D>
+__global__ __launch_bounds__(THREADS) void qk_split_h2_kernel(const float* __restrict__ qkv, const float* __restrict__ rowmax,
+                                                              __bf16* __restrict__ ws, int C, int L, float qscale, float one) {
+  const int heads = C / D;
+  const int which = blockIdx.y / heads, head = blockIdx.y - which * heads, b = blockIdx.z;
+  const int l = blockIdx.x * THREADS + threadIdx.x;
+  // the head's balance: exponents of max |q| qscale and max |k| (every thread reads the 2 D row maxima: 128 bytes, L2-resident)
+  float mq = 0.f, mk = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    mq = fmaxf(mq, rowmax[(size_t)b * 2 * C + head * D + d]);
+    mk = fmaxf(mk, rowmax[(size_t)b * 2 * C + C + head * D + d]);
+  }
+  mq *= qscale;
+  const int eq = (int)((__builtin_bit_cast(unsigned, mq) >> 23) & 0xffu), ek = (int)((__builtin_bit_cast(unsigned, mk) >> 23) & 0xffu);
+  int a = (eq == 0 || ek == 0 || eq == 255 || ek == 255) ? 0 : (eq - ek) / 2;      // k 2^a, q 2^-a (zero / inf / NaN rows: no balance)
+  a = a < -60 ? -60 : (a > 60 ? 60 : a);
+  const float sc = which == 0 ? qscale * __builtin_bit_cast(float, (unsigned)(127 - a) << 23) : __builtin_bit_cast(float, (unsigned)(127 + a) << 23);
+  if (l >= L) return;
+  const float* src = qkv + ((size_t)b * 3 * C + (size_t)which * C + (size_t)head * D) * L;
+  const size_t piece = (size_t)L * D;
+  __bf16* pair = ws + ((size_t)b * heads + head) * 9 * piece;
+  const float up = (float)(1 << QK_SHIFT) * one;
+  typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+  const f16x2v dn = {(_Float16)(1.0f / (1 << QK_SHIFT)), (_Float16)(1.0f / (1 << QK_SHIFT))};
+  unsigned h[4][D / 2];          // x0, x0 2^-8, x1 2^8, x1 as packed fp16 pairs (channels 2 j, 2 j + 1)
+#pragma unroll
+  for (int j = 0; j < D / 2; ++j) {
+    float xa = src[(size_t)(2 * j) * L + l] * sc, xb = src[(size_t)(2 * j + 1) * L + l] * sc;
+    // the fp32 products and the packed first pieces are made opaque: left alone the compiler rounds x0 twice -- once from the
+    // fp32 product for the stored piece, once from the EXACT product (v_fma_mixlo_f16) for the residual -- and where the two
+    // differ by an ulp the stored pieces no longer add up (found by tools/h2_qk_debug.py: 4e-4 instead of 5e-7)
+    asm("" : "+v"(xa), "+v"(xb));
+    unsigned u0 = __builtin_bit_cast(unsigned, f16x2v{(_Float16)xa, (_Float16)xb});
+    asm("" : "+v"(u0));
+    const f16x2v x0 = __builtin_bit_cast(f16x2v, u0);
+    const float ra = xa - (float)x0[0], rb = xb - (float)x0[1];            // exact
+    const f16x2v x1s = {(_Float16)(ra * up), (_Float16)(rb * up)}, x1 = {(_Float16)ra, (_Float16)rb};
+    h[0][j] = __builtin_bit_cast(unsigned, x0);
+    h[1][j] = __builtin_bit_cast(unsigned, x0 * dn);
+    h[2][j] = __builtin_bit_cast(unsigned, x1s);
+    h[3][j] = __builtin_bit_cast(unsigned, x1);
+  }
+  // Q: pieces 0 (q0) and 1 (q1 2^8); K: pieces 2 .. 5
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if (which == 0 && (p == 1 || p == 3)) continue;
+    const int slot = which == 0 ? (p == 0 ? 0 : 1) : 2 + p;
+    u32x4* o = reinterpret_cast<u32x4*>(pair + slot * piece + (size_t)l * D);
+#pragma unroll
+    for (int j = 0; j < D / 8; ++j) o[j] = u32x4{h[p][4 * j], h[p][4 * j + 1], h[p][4 * j + 2], h[p][4 * j + 3]};
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // V of qkv [B][3C][L] (fp32)  ->  two fp16 pieces of V * 2^s, s per channel row, in the V region of the pre-split workspace:
@@ -250,18 +334,18 @@ __global__ __launch_bounds__(THREADS) void v_split_h2_kernel(const float* __rest
 template <int D, int NQ>
 __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf16* __restrict__ ws, float* __restrict__ out,
                                                                       float* __restrict__ lse2, int C, int L, float one) {
-  static_assert(D == 16, "head dim: the operand sharing below is that of two terms per MFMA");
+  static_assert(D == 16, "head dim: two terms share one MFMA's 32 contraction slots");
   static_assert(NQ == 4, "the stage pipeline is written for four query tiles per wave");
-  constexpr int NKS = 2;                   // K operand sets per 16 keys: (k0 | k1) for MFMAs 0 and 1, (k0 | k2) for MFMA 2
-  constexpr int TPM = 32 / D;              // terms per QK^T MFMA
-  constexpr int NQK = 6 / TPM;             // QK^T MFMAs per 16x16 score tile
+  constexpr int NKP = 4;                   // K pieces (see QK_SHIFT)
+  constexpr int NKS = 2;                   // K operand sets per 16 keys = QK^T MFMAs per 16x16 score tile
+  constexpr int NQK = NKS;
   constexpr int MT = D / 16;               // 16-row tiles of the output
   constexpr int KROWB = D * 2;             // bytes per key of one K piece
   constexpr int KPART = KT * KROWB;
   constexpr int VROWB = KT * 2 + 8;        // bytes per d row of one V piece (+8: the 16 rows of an operand read spread over banks)
   constexpr int VPART = D * VROWB;
   constexpr int QB = 64 * NQ;              // queries per workgroup (4 waves x NQ tiles of 16)
-  constexpr int VBASE = 3 * KPART;
+  constexpr int VBASE = NKP * KPART;
   constexpr int BUFB = VBASE + 2 * VPART;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][BUFB];
 
@@ -273,37 +357,45 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
   const int ntiles = L / KT;
 
   // contraction slots of this lane: 8 consecutive d of one term
-  const int doff = (TPM == 2) ? 8 * (g & 1) : 8 * g;
-  const bool hi = (TPM == 2) && (g >> 1);
+  const int doff = 8 * (g & 1);
+  const bool hi = g >> 1;
 
   const size_t piece_n = (size_t)L * D;
   const __bf16* wsq = ws + ((size_t)b * gridDim.y + head) * 9 * piece_n;
-  // Q operands of the wave's four query tiles, in registers for the whole kernel: [query tile][MFMA]
+  // Q operands of the wave's four query tiles, in registers for the whole kernel: [query tile][MFMA].  The workspace holds q0 and
+  // q1 2^8; q0 2^-8 and q1 are their multiples (v_pk_mul_f16 by 2^-8: exact, or rounded into fp16's subnormals like the split
+  // pass would have).
   u32x4 qop[NQ][NQK];
+  {
+    static_assert(QK_SHIFT == 8, "packed fp16 constant below");
+    const unsigned dn2 = 0x1c001c00u;                // (2^-8, 2^-8) as packed fp16
 #pragma unroll
-  for (int qt = 0; qt < NQ; ++qt) {
-    const int q = qblk0 + qt * 16 + i16;
-    u32x4 piece[3];
+    for (int qt = 0; qt < NQ; ++qt) {
+      const int q = qblk0 + qt * 16 + i16;
+      const u32x4 q0 = *reinterpret_cast<const u32x4*>(wsq + (size_t)q * D + doff);
+      const u32x4 q1s = *reinterpret_cast<const u32x4*>(wsq + piece_n + (size_t)q * D + doff);
+      const u32x4 sel = hi ? q1s : q0;  // this lane's half of the pairing: (q0, q0 2^-8) on the low slots, (q1 2^8, q1) on the high ones
+      // (asm: written as four v2f16 multiplications in C, hipcc 7.2 -O3 emits ONE v_pk_mul_f16 and broadcasts word 0 over the tuple)
+      unsigned dnw[4];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) piece[p] = *reinterpret_cast<const u32x4*>(wsq + p * piece_n + (size_t)q * D + doff);
-#pragma unroll
-    for (int j = 0; j < NQK; ++j) qop[qt][j] = hi ? piece[TERM_B[2 * j + 1]] : piece[TERM_B[2 * j]];
+      for (int w = 0; w < 4; ++w) asm("v_pk_mul_f16 %0, %1, %2" : "=v"(dnw[w]) : "v"(sel[w]), "v"(dn2));
+      qop[qt][0] = sel;                                      // against K set 0 = (k0 | k0 2^-8)
+      qop[qt][1] = u32x4{dnw[0], dnw[1], dnw[2], dnw[3]};    // against K set 1 = (k1 2^8 | k1)
+    }
   }
-  int kaddr[NKS];          // K operand set s: the A operand of MFMA 2 s (and, for s = 0, of MFMA 1)
+  int kaddr[NKS];          // K operand set s: the A operand of MFMA s
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) kaddr[ks] = (hi ? TERM_A[4 * ks + 1] : TERM_A[4 * ks]) * KPART + i16 * KROWB + doff * 2;
-  static_assert(TERM_A[0] == TERM_A[2] && TERM_A[1] == TERM_A[3], "MFMAs 0 and 1 share their K operand");
+  for (int ks = 0; ks < NKS; ++ks) kaddr[ks] = (2 * ks + (hi ? 1 : 0)) * KPART + i16 * KROWB + doff * 2;
   const int vaddr = i16 * VROWB + 8 * g;
 
-  // staging: chunk c = i * 256 + tid of the tile's 16-byte chunks (three K pieces, then two V pieces), copied as they are;
-  // the chunk count is not a multiple of 256 at d_head 16: the spare threads of the last round repeat earlier V chunks
-  constexpr int NKC = 3 * KT * D / 8, NVC = 2 * D * 8, NCH = NKC + NVC, NLD = (NCH + THREADS - 1) / THREADS;
+  // staging: chunk c = i * 256 + tid of the tile's 16-byte chunks (four K pieces, then two V pieces), copied as they are
+  constexpr int NKC = NKP * KT * D / 8, NVC = 2 * D * 8, NCH = NKC + NVC, NLD = (NCH + THREADS - 1) / THREADS;
   static_assert(NLD * THREADS - NCH <= NVC, "staging geometry");
   const unsigned char* gsrc[NLD];
   int lds_off[NLD], gstep[NLD];
   u32x4 stage[NLD];
   {
-    const __bf16* ksp = wsq + 3 * piece_n;
+    const __bf16* ksp = wsq + 2 * piece_n;
     const __bf16* vsp = wsq + 6 * piece_n;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -380,14 +472,17 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
       for (int ks = 0; ks < NKS; ++ks) kop[kt][ks] = *reinterpret_cast<const u32x4*>(kb + kaddr[ks] + kt * 16 * KROWB);
   };
   // MFMA n of Q K^T for query tile qt into S[par]: the four key tiles' chains round robin (a dependent pair is 4 apart)
-  // rollk >= 0: this is the last query tile of the key tile -- a K operand set is free once its last MFMA has been issued
-  // (set 0 after MFMA 1, set 1 after MFMA 2) and is fetched for the next key tile (buffer rollk) right behind it
+  // rollk >= 0: this is the last query tile of the key tile -- K operand set j is free once MFMA j has been issued and is fetched
+  // for the next key tile (buffer rollk) right behind it
   auto qk_mfma = [&](int qt, int par, int n, int rollk = -1) {
-    const int j = n >> 2, kt = n & 3, ks = j >> 1;
-    if (!((HDIFF_MUTANT & 4) && j == 2))        // (mutation test: the (k0 q2 + k2 q0) MFMA dropped)
-      S[par][kt] = mfma_bf16(kop[kt][ks], qop[qt][j], j == 0 ? negm4[qt] : S[par][kt]);      // the chain starts from -m
+    const int j = n >> 2, kt = n & 3;
+    u32x4 qb = qop[qt][j];
+    if ((HDIFF_MUTANT & 4) && j == 1)            // (mutation test: the low five bits of the small Q pieces dropped: 2^-17 of q)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) qb[w] &= 0xffe0ffe0u;
+    S[par][kt] = mfma_f16(kop[kt][j], qb, j == 0 ? negm4[qt] : S[par][kt]);      // the chain starts from -m, large terms first
     if (H2_ABL & 2) return;
-    if (rollk >= 0 && j >= 1) kop[kt][ks] = *reinterpret_cast<const u32x4*>(smem[rollk] + kaddr[ks] + kt * 16 * KROWB);
+    if (rollk >= 0) kop[kt][j] = *reinterpret_cast<const u32x4*>(smem[rollk] + kaddr[j] + kt * 16 * KROWB);
   };
   constexpr int NPV = 6 * MT;
   // MFMA n of O[qt] += P V with P from pop[par]: per 32-key chunk and row tile the small terms first
@@ -472,9 +567,10 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
       constexpr int NV = 56;
 #pragma unroll
       for (int i = 0; i < NM; ++i) {
-        if constexpr (PEND) {          // q q p q q p ...
-          if (i % 3 == 2) pv_mfma(pv_q, par ^ 1, i / 3);
-          else qk_mfma(qk_q, par ^ 1, i - i / 3, rollk);
+        if constexpr (PEND) {          // the P V MFMAs spread evenly between the Q K^T ones: q p q q p q p q q p ...
+          const int npv = (i + 1) * NPV / NM, ppv = i * NPV / NM;
+          if (npv != ppv) pv_mfma(pv_q, par ^ 1, ppv);
+          else qk_mfma(qk_q, par ^ 1, i - ppv, rollk);
         } else qk_mfma(qk_q, par ^ 1, i, rollk);
 #pragma unroll
         for (int n = NV * i / NM; n < NV * (i + 1) / NM; ++n) vstep(n);
@@ -526,6 +622,23 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
   load_k(0);
 #pragma unroll
   for (int n = 0; n < 4 * NQK; ++n) qk_mfma(0, 0, n);
+#if H2_DIAG == 2
+  // scores of (query tile 0 of wave 0, key tile 0) of the first workgroup of every pair: S[0][kt][r] = s(query qblk0 + i16, key 16 kt + 4 g + r)
+  if (tile.x == 0 && wave == 0) {
+    float* dg = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(const_cast<__bf16*>(wsq + 8 * piece_n)) + 128) + lane * 16;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dg[kt * 4 + r] = S[0][kt][r];
+    // ... and the operands the lane holds: Q sets 0, 1 of query tile 0 and K sets 0, 1 of key tile 0 (re-read from LDS)
+    unsigned* du = reinterpret_cast<unsigned*>(dg - lane * 16 + 64 * 16) + lane * 16;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      du[w] = qop[0][0][w]; du[4 + w] = qop[0][1][w];
+      du[8 + w] = reinterpret_cast<const unsigned*>(smem[0] + kaddr[0])[w]; du[12 + w] = reinterpret_cast<const unsigned*>(smem[0] + kaddr[1])[w];
+    }
+  }
+#endif
   tile_fn(std::true_type{}, 0);
   for (int t = 1; t < ntiles; ++t) tile_fn(std::false_type{}, t);
 #pragma unroll
@@ -576,7 +689,10 @@ void launch_v_split_h2(const float* qkv, void* ws, int B, int C, int heads, int 
   else hipLaunchKernelGGL((v_split_h2_kernel<32>), dim3(C, B), dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, 1.0f);
 }
 
-// The fp16-pair P.V kernel on the pre-split workspace (Q, K: bf16 triples written by launch_qk_split3; V: this file).
+// Bytes the d_head 16 kernel keeps behind the (sample, head) pairs of the workspace: the Q / K row maxima
+int64_t mha_fwd_h2_tail_bytes(int B, int C) { return ((int64_t)B * 2 * C * 4 + 255) / 256 * 256; }
+
+// The d_head 16 forward on fp16 pairs (scores: four balanced products; P.V: three) on its own operand layout in the workspace.
 // Returns false when the shape is not covered or the workspace is missing (the caller then runs the bf16-triple kernels).
 bool launch_mha_fwd_h2(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
                        int64_t ws_bytes, hipStream_t stream) {
@@ -584,7 +700,10 @@ bool launch_mha_fwd_h2(const float* qkv, float* o, float* lse2, int B, int C, in
   if (!mha_fwd_h2_enabled() || need == 0 || ws == nullptr || ws_bytes < need) return false;
   const int D = C / heads;
   if (D != 16) return false;
-  launch_qk_split3(qkv, ws, B, C, heads, L, qscale, stream);
+  float* rowmax = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + need - mha_fwd_h2_tail_bytes(B, C));
+  hipLaunchKernelGGL(qk_rowmax_kernel, dim3(2 * C, B), dim3(THREADS), 0, stream, qkv, rowmax, C, L);
+  hipLaunchKernelGGL((qk_split_h2_kernel<16>), dim3(cdiv(L, 256), 2 * heads, B), dim3(THREADS), 0, stream, qkv, rowmax, (__bf16*)ws, C, L,
+                     qscale, 1.0f);
   launch_v_split_h2(qkv, ws, B, C, heads, L, stream);
   hipLaunchKernelGGL((mha_flash_fwd_h2_kernel<16, 4>), dim3(L / 256, heads, B), dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2,
                      C, L, 1.0f);

@@ -486,7 +486,7 @@ namespace hdiff {
 int64_t mha_fwd_x3p_workspace(int B, int C, int heads, int L) {
   const int D = C / heads;
   if ((D != 16 && D != 32) || L % 256 != 0 || L < 512) return 0;
-  return (int64_t)B * 3 * C * L * 6;
+  return (int64_t)B * 3 * C * L * 6 + mha_fwd_h2_tail_bytes(B, C);      // nine 2-byte pieces per element + the d_head 16 kernel's row maxima
 }
 
 // Q (pre-scaled) and K alone as bf16 triples into the workspace (for attention_h2.hip, which writes its own V pieces)
