@@ -692,6 +692,15 @@ void launch_v_split_h2(const float* qkv, void* ws, int B, int C, int heads, int 
 // Bytes the d_head 16 kernel keeps behind the (sample, head) pairs of the workspace: the Q / K row maxima
 int64_t mha_fwd_h2_tail_bytes(int B, int C) { return ((int64_t)B * 2 * C * 4 + 255) / 256 * 256; }
 
+// Q and K as fp16 score operands (pieces 0, 1 and 2 .. 5 of every pair; d_head 16 / 32), the row maxima in the workspace's tail
+void launch_qk_split_h2(const float* qkv, void* ws, int B, int C, int heads, int L, float qscale, hipStream_t stream) {
+  float* rowmax = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + mha_fwd_x3p_workspace(B, C, heads, L) - mha_fwd_h2_tail_bytes(B, C));
+  hipLaunchKernelGGL(qk_rowmax_kernel, dim3(2 * C, B), dim3(THREADS), 0, stream, qkv, rowmax, C, L);
+  dim3 grid(cdiv(L, 256), 2 * heads, B);
+  if (C / heads == 16) hipLaunchKernelGGL((qk_split_h2_kernel<16>), grid, dim3(THREADS), 0, stream, qkv, rowmax, (__bf16*)ws, C, L, qscale, 1.0f);
+  else hipLaunchKernelGGL((qk_split_h2_kernel<32>), grid, dim3(THREADS), 0, stream, qkv, rowmax, (__bf16*)ws, C, L, qscale, 1.0f);
+}
+
 // The d_head 16 forward on fp16 pairs (scores: four balanced products; P.V: three) on its own operand layout in the workspace.
 // Returns false when the shape is not covered or the workspace is missing (the caller then runs the bf16-triple kernels).
 bool launch_mha_fwd_h2(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
@@ -700,10 +709,7 @@ bool launch_mha_fwd_h2(const float* qkv, float* o, float* lse2, int B, int C, in
   if (!mha_fwd_h2_enabled() || need == 0 || ws == nullptr || ws_bytes < need) return false;
   const int D = C / heads;
   if (D != 16) return false;
-  float* rowmax = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + need - mha_fwd_h2_tail_bytes(B, C));
-  hipLaunchKernelGGL(qk_rowmax_kernel, dim3(2 * C, B), dim3(THREADS), 0, stream, qkv, rowmax, C, L);
-  hipLaunchKernelGGL((qk_split_h2_kernel<16>), dim3(cdiv(L, 256), 2 * heads, B), dim3(THREADS), 0, stream, qkv, rowmax, (__bf16*)ws, C, L,
-                     qscale, 1.0f);
+  launch_qk_split_h2(qkv, ws, B, C, heads, L, qscale, stream);
   launch_v_split_h2(qkv, ws, B, C, heads, L, stream);
   hipLaunchKernelGGL((mha_flash_fwd_h2_kernel<16, 4>), dim3(L / 256, heads, B), dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2,
                      C, L, 1.0f);

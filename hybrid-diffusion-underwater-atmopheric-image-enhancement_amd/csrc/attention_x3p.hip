@@ -146,25 +146,35 @@ __global__ __launch_bounds__(THREADS) void qkv_split3_kernel(const float* __rest
 // PIPE (PVH only): both query groups' score chains are issued before the first group's exp / split stream, so that a wave's own
 // matrix work (the second group's 12 MFMAs, then the first group's P.V) runs beside its vector work instead of only the other
 // wave's; the references of the two groups are independent (one per query), so the order is free.
+// Round 5 (PVH): the scores on fp16 pairs with a balance per product term as well (attention_h2.hip has the scheme and its
+// error analysis): K pieces k0, k0 2^-8, k1 2^8 (, k1), Q pieces q0, q1 2^8 from the workspace and q0 2^-8 (, q1) made in
+// registers; NQT product terms (piece i of K against piece i of Q), each two k-steps of v_mfma_f32_32x32x16_f16.  NQT = 4 is
+// the d_head 16 kernel's choice (error of S 1.02x the fp32 chain's); NQT = 3 drops k1 q1 (1.14x) and needs no more registers
+// than the bf16 triples did.
+#ifndef X3P_NQT
+#define X3P_NQT 3
+#endif
 template <int D, bool PVH = false, bool PIPE = false>
 __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __bf16* __restrict__ ws, float* __restrict__ out,
                                                                       float* __restrict__ lse2, int C, int L, float one) {
   static_assert(D == 16 || D == 32, "head dim");
   static_assert(!PVH || D == 32, "the fp16-pair P.V form of this kernel is the d_head 32 one");
   constexpr int NPC = PVH ? 2 : 3;             // pieces of V and of P
+  constexpr int NKP = PVH ? X3P_NQT : 3;       // K pieces staged (PVH: = score product terms)
+  constexpr int NQT = PVH ? X3P_NQT : 6;       // score product terms
   constexpr int KS = D / 16;                   // k-steps of the QK^T product
   constexpr int NPV = (D == 16) ? 4 : 6;       // P.V MFMAs per 16 keys
   constexpr int KROWB = D * 2 + 16;            // bytes per key of one K piece in LDS (+16: conflict-free ds_read_b128)
   constexpr int KPART = KT * KROWB;
   constexpr int VROWB = KT * 2 + 8;            // bytes per d row of one V piece (+8: rows spread over the banks)
   constexpr int VPART = D * VROWB;
-  constexpr int NKC = 3 * KT * D / 8;          // 16-byte chunks of a K tile (all pieces)
+  constexpr int NKC = NKP * KT * D / 8;        // 16-byte chunks of a K tile (all pieces)
   constexpr int NVC = NPC * D * 8;             // 16-byte chunks of a V tile
   constexpr int NLD = (NKC + NVC) / THREADS;   // chunks per thread: 3 (d 16), 6 (d 32)
   static_assert((NKC + NVC) % THREADS == 0, "staging geometry");
   constexpr int QB = 256;                      // queries per workgroup: 4 waves x 2 groups of 32
 
-  constexpr int VBASE = 3 * KPART;                                         // one buffer = K pieces, V pieces, one row of zeros
+  constexpr int VBASE = NKP * KPART;                                       // one buffer = K pieces, V pieces, one row of zeros
   constexpr int BUFB = (VBASE + NPC * VPART + VROWB + 15) / 16 * 16;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][BUFB];
 
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
   const int qblk0 = tile.x * QB + wave * 64;
   const size_t piece = (size_t)L * D;
   const __bf16* qs = ws + ((size_t)b * heads + head) * 9 * piece;
-  const __bf16* ks = qs + 3 * piece;
+  const __bf16* ks = qs + (PVH ? 2 : 3) * piece;      // PVH: Q pieces 0, 1, K pieces 2 .. 5 (launch_qk_split_h2)
   const __bf16* vs = qs + 6 * piece;
   const int ntiles = L / KT;
 
@@ -187,15 +197,29 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
   }
 
   // Q operands (B of S^T = K Q^T): lane (query l31, half h) holds d = 16 ks + 8 h .. + 7 of each piece
-  u32x4 qop[2][3][KS];
+  constexpr int NQP = PVH ? NQT : 3;           // Q pieces held
+  u32x4 qop[2][NQP][KS];
 #pragma unroll
   for (int G = 0; G < 2; ++G) {
     const int q = qblk0 + 32 * G + l31;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < (PVH ? 2 : 3); ++p)
 #pragma unroll
       for (int s = 0; s < KS; ++s)
         qop[G][p][s] = *reinterpret_cast<const u32x4*>(qs + p * piece + (size_t)q * D + 16 * s + 8 * h);
+    if constexpr (PVH) {
+      // q0 2^-8 (and q1 = q1 2^8 2^-8): packed fp16 multiplications by 2^-8 (asm: see attention_h2.hip)
+      const unsigned dn2 = 0x1c001c00u;
+#pragma unroll
+      for (int p = 2; p < NQP; ++p)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          unsigned w4[4];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) asm("v_pk_mul_f16 %0, %1, %2" : "=v"(w4[w]) : "v"(qop[G][p - 2][s][w]), "v"(dn2));
+          qop[G][p][s] = u32x4{w4[0], w4[1], w4[2], w4[3]};
+        }
+    }
   }
 
   // staging: chunk c = i * 256 + tid of the tile's 16-byte chunks (K pieces first, then V pieces)
@@ -266,10 +290,10 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
 #pragma unroll
   for (int r = 0; r < 16; ++r) negm16[r] = 0.f;
 
-  auto load_k = [&](int buf, int kb, u32x4 (&kop)[3][KS]) {
+  auto load_k = [&](int buf, int kb, u32x4 (&kop)[NKP][KS]) {
     const unsigned char* kbuf = smem[buf] + kb * 32 * KROWB + kaddr;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NKP; ++p)
 #pragma unroll
       for (int s = 0; s < KS; ++s) kop[p][s] = *reinterpret_cast<const u32x4*>(kbuf + p * KPART + 32 * s);
   };
@@ -286,8 +310,21 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
         vop[ab][kind] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
       }
   };
-  auto qk = [&](const u32x4 (&kop)[3][KS], int G, f32x16 c) {
+  auto qk = [&](const u32x4 (&kop)[NKP][KS], int G, f32x16 c) {
     f32x16 S = c;                                  // the chain starts from -m: the accumulator holds s - m
+    if constexpr (PVH) {                           // fp16 pairs: piece i of K against piece i of Q, large term first
+#pragma unroll
+      for (int term = 0; term < NQT; ++term)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          u32x4 qb = qop[G][term][s];
+          if ((HDIFF_MUTANT & 2) && term == 1)       // (mutation test: the low five bits of q1 2^8 dropped: 2^-17 of q)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) qb[w] &= 0xffe0ffe0u;
+          S = mfma32h(kop[term][s], qb, S);
+        }
+      return S;
+    }
 #pragma unroll
     for (int term = 0; term < 6; ++term)
 #pragma unroll
@@ -378,7 +415,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
   __syncthreads();
   stage_load(ntiles > 1 ? 1 : 0);
   {
-    u32x4 K0[3][KS];
+    u32x4 K0[NKP][KS];
     load_k(0, 0, K0);
     const f32x16 s0 = qk(K0, 0, negm16), s1 = qk(K0, 1, negm16);       // C = 0 here
     float tm = fmaxf(s0[0], s1[0]);
@@ -396,7 +433,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3p_kernel(const __b
     for (int r = 0; r < 16; ++r) negm16[r] = -tm;
   }
   auto block = [&](int buf, int kb) {
-    u32x4 kop[3][KS], vop[2][NVK];
+    u32x4 kop[NKP][KS], vop[2][NVK];
     load_k(buf, kb, kop);
     load_v(buf, kb, vop);
     if constexpr (PVH && PIPE) {
@@ -518,7 +555,7 @@ bool launch_mha_fwd_x3p(const float* qkv, float* o, float* lse2, int B, int C, i
     hipLaunchKernelGGL((mha_flash_fwd_x3p_kernel<16>), grid, dim3(THREADS), 0, stream, (const __bf16*)ws, o, lse2, C, L, 1.0f);
   } else if (wide && mha_fwd_h2_enabled()) {
     // P.V on fp16 pairs: Q, K as bf16 triples, V as fp16 pairs with per-row powers of two (the V region of the same workspace)
-    launch_qk_split3(qkv, ws, B, C, heads, L, qscale, stream);
+    launch_qk_split_h2(qkv, ws, B, C, heads, L, qscale, stream);      // scores on fp16 pairs too (round 5)
     launch_v_split_h2(qkv, ws, B, C, heads, L, stream);
     static const char* pe = getenv("HDIFF_X3P_PIPE");       // dev knob (A/B): 0 = the straight (group, block) order (2.129 vs 2.092 ms at L = 16384, B = 2)
     if (!(pe && atoi(pe) == 0))

@@ -154,6 +154,7 @@ bool launch_mha_fwd_h2w(const float* qkv, float* o, float* lse2, int B, int C, i
                         int64_t ws_bytes, hipStream_t stream);
 int64_t mha_fwd_h2_tail_bytes(int B, int C);      // bytes behind the pairs of the workspace (Q / K row maxima of the d_head 16 kernel)
 bool mha_fwd_h2_enabled();          // dev knob HDIFF_PV=bf16x3 keeps the bf16-triple P.V kernels
+void launch_qk_split_h2(const float* qkv, void* ws, int B, int C, int heads, int L, float qscale, hipStream_t stream);   // Q, K as fp16 score operands
 void launch_v_split_h2(const float* qkv, void* ws, int B, int C, int heads, int L, hipStream_t stream);   // V as fp16 pairs, d_head 16 / 32
 bool launch_mha_fwd_x3(const float* qkv, const void* ws /* pre-split operands or NULL */, float* o, float* lse2, int B, int C,
                        int heads, int L, float qscale, hipStream_t stream);
