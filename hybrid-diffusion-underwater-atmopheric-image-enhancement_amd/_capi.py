@@ -160,17 +160,19 @@ def build(verbose: bool = False, clean: bool = False) -> str:
 
 
 MUTANT_PATH = os.path.join(CSRC, "build", "libhdiff_mutant.so")
+MUTANT2_PATH = os.path.join(CSRC, "build", "libhdiff_mutant2.so")
 
 
 def build_mutant(verbose: bool = False) -> str:
-    """Test infrastructure (tests/test_gpu_mutation.py): the library with ONE lowest-order piece product dropped in each
-    split-operand forward kernel (csrc/common.h, HDIFF_MUTANT).  Never loaded by the product."""
-    res = subprocess.run(["make", "-C", CSRC, "-j4", "mutant"], capture_output=True, text=True)
+    """Test infrastructure (tests/test_gpu_mutation.py): the library with ONE low-order piece product damaged in each
+    split-operand kernel (csrc/common.h lists the HDIFF_MUTANT bits), and a second one with the third-piece terms of dS in the
+    attention backward alone.  Never loaded by the product."""
+    res = subprocess.run(["make", "-C", CSRC, "-j4", "mutant", "mutant2"], capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:])
         print(res.stderr[-4000:])
-    if res.returncode != 0 or not os.path.isfile(MUTANT_PATH):
-        raise RuntimeError("building libhdiff_mutant.so failed")
+    if res.returncode != 0 or not os.path.isfile(MUTANT_PATH) or not os.path.isfile(MUTANT2_PATH):
+        raise RuntimeError("building libhdiff_mutant.so / libhdiff_mutant2.so failed")
     return MUTANT_PATH
 
 

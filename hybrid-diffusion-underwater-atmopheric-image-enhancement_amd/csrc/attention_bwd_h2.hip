@@ -412,12 +412,13 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
             }
             S[jq] = acc;
             acc = negd[jq];
+            // (mutation test, bit 16: the cross product o0 v1 dropped -- at d 16 with its MFMA partner o1 v1, a 2^-22 term)
             if constexpr (D == 16) {        // (o0 v1 + o1 v1), then (o0 v0 + o1 v0): the small products first
-              acc = mfma_f16(oA[jq][0], vB[kt][1], acc);
+              if (!(HDIFF_MUTANT & 16)) acc = mfma_f16(oA[jq][0], vB[kt][1], acc);
               acc = mfma_f16(oA[jq][0], vB[kt][0], acc);
             } else {
               acc = mfma_f16(oA[jq][1], vB[kt][1], acc);
-              acc = mfma_f16(oA[jq][0], vB[kt][1], acc);
+              if (!(HDIFF_MUTANT & 16)) acc = mfma_f16(oA[jq][0], vB[kt][1], acc);
               acc = mfma_f16(oA[jq][1], vB[kt][0], acc);
               acc = mfma_f16(oA[jq][0], vB[kt][0], acc);
             }
@@ -463,8 +464,11 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
             if (MT > 1) load_transposed(mt, qTm, oTm);       // d 32: one M tile's operands at a time (registers)
 #pragma unroll
             for (int term = 5; term >= 0; --term) {      // small terms first
-              if (term < 3) dVt[kt][mt] = mfma_f16((MT == 1 ? oT0 : oTm)[TERM_A[term]], Pp[TERM_B[term]], dVt[kt][mt]);   // o0 p1, o1 p0, o0 p0
-              dKt[kt][mt] = mfma_bf16((MT == 1 ? qT0 : qTm)[TERM_A[term]], Sp[TERM_B[term]], dKt[kt][mt]);
+              // (mutation test, bit 32: the product o1 p0 of dV^T dropped; bit 64: the 2^-16 term q0 s2 of dK^T -- and k0 s2 of dQ^T below)
+              if (term < 3 && !((HDIFF_MUTANT & 32) && term == 1))
+                dVt[kt][mt] = mfma_f16((MT == 1 ? oT0 : oTm)[TERM_A[term]], Pp[TERM_B[term]], dVt[kt][mt]);   // o0 p1, o1 p0, o0 p0
+              if (!((HDIFF_MUTANT & 64) && term == 5))
+                dKt[kt][mt] = mfma_bf16((MT == 1 ? qT0 : qTm)[TERM_A[term]], Sp[TERM_B[term]], dKt[kt][mt]);
             }
           }
         }
@@ -484,7 +488,8 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
           for (int mt = 0; mt < MT; ++mt) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int term = 5; term >= 0; --term) acc = mfma_bf16(kT[mt][TERM_A[term]], sT[TERM_B[term]], acc);
+            for (int term = 5; term >= 0; --term)
+              if (!((HDIFF_MUTANT & 64) && term == 5)) acc = mfma_bf16(kT[mt][TERM_A[term]], sT[TERM_B[term]], acc);
             dQt[sub][jq][mt] = acc;
           }
         }

@@ -489,7 +489,11 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
   auto pv_mfma = [&](int qt, int par, int n) {
     const int c = n / (3 * MT), r = n - c * 3 * MT, mt = r / 3, term = r - mt * 3;
     const int pv_v = term == 0 ? 1 : 0, pv_p = term == 1 ? 1 : 0;                      // (v1, p0), (v0, p1), (v0, p0)
-    O[mt][qt] = mfma_f16(vop[pv_v][mt][c], pop[par][pv_p][c], O[mt][qt]);
+    u32x4 pb = pop[par][pv_p][c];
+    if ((HDIFF_MUTANT & 8) && pv_p == 1)         // (mutation test: the low five bits of every second piece of P dropped: 2^-17 of P)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) pb[w] &= 0xffe0ffe0u;
+    O[mt][qt] = mfma_f16(vop[pv_v][mt][c], pb, O[mt][qt]);
   };
   // P = exp2(S) of one stage (16 queries x 64 keys of this wave; 16 values per lane), its two fp16 pieces packed as the
   // B operands of P.V, and the lane's two partial row sums

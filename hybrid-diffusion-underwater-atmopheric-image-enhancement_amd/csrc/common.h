@@ -117,11 +117,19 @@ void launch_conv1x1_x3(const Conv1x1X3K& k, int B, hipStream_t stream);
 
 int contraction_mode();   // HDIFF_CONTRACT_*
 
-// Mutation switch of the parity suite's own sensitivity test (tests/test_gpu_mutation.py): a library built with
-// -DHDIFF_MUTANT=<mask> silently drops ONE lowest-order piece product (bf16 pieces 0 x 2: 2^-16 of the product) --
-// bit 0 in the split-bf16 3x3 and 1x1 convolutions (the 3x3's fp16-pair form: the low five bits of every activation's second piece), bit 1 in the
-// d_head 32 attention forward (attention_x3p.hip), bit 2 in the
-// score product of the d_head 16 attention forward (attention_h2.hip).  The tightened model-level tests must FAIL on it.
+// Mutation switch of the parity suite's own sensitivity tests (tests/test_gpu_mutation.py): a library built with
+// -DHDIFF_MUTANT=<mask> silently damages ONE low-order piece product per bit, at the 2^-16 / 2^-17 level of the product --
+//   bit 0 (1)   the split-bf16 3x3 and 1x1 convolutions: the term w0 x2 dropped (the 3x3's fp16-pair form: the low five bits of
+//               every activation's second piece masked)
+//   bit 1 (2)   the d_head 32 attention forward (attention_x3p.hip): the low five bits of the second Q piece of the scores masked
+//   bit 2 (4)   the d_head 16 attention forward (attention_h2.hip): the same in its score product
+//   bit 3 (8)   the d_head 16 attention forward: the low five bits of every second piece of P masked (the P V product)
+//   bit 4 (16)  the attention backward (attention_bwd_h2.hip): the cross product o0 v1 of dP = dO V^T dropped
+//   bit 5 (32)  the attention backward: the product o1 p0 of dV^T = dO^T P dropped
+//   bit 6 (64)  the attention backward: the 2^-16 terms q0 s2 of dK^T and k0 s2 of dQ^T (third bf16 piece of dS) dropped
+// `make mutant` builds bits 0, 1, 2, 4, 5 into build/libhdiff_mutant.so, `make mutant2` bits 3 and 6 into build/libhdiff_mutant2.so (bits 2
+// and 3 both end in the d_head 16 forward's output, bits 4 and 6 both in dK / dQ: one library could not tell which of them a red test
+// has seen).  The float64 error-class tests must FAIL on them.
 #ifndef HDIFF_MUTANT
 #define HDIFF_MUTANT 0
 #endif

@@ -21,7 +21,10 @@ CONTRACT_INDEPENDENT = {"test_small_ops_match_torch",
                         "test_ddpm_step_bit_exact_and_nan_flag", "test_ddpm_step_loop_bookkeeping", "test_q_sample_bit_exact_and_clip",
                         "test_randn_moments_and_determinism", "test_groupnorm_scale_shift", "test_groupnorm_fused_finalize_equals_two_launches",
                         "test_linear_rows_multi_equals_the_launches_it_replaces", "test_flash_attention_x3p_kernel_at_d_head_16_behind_its_dev_knob", "test_conv1x1_direct_gemm_path",
-                        "test_conv1x1_and_5x5_stride2"}
+                        "test_conv1x1_and_5x5_stride2",
+                        # these run both modes side by side themselves
+                        "test_split_bf16_attention_backward_is_another_program_fp32_class_and_reproducible",
+                        "test_attention_backward_fp16_pairs_error_class_every_pair", "test_attention_backward_fp16_pairs_ranges"}
 CONTRACT_MODES = ("f32", "bf16x3")
 
 

@@ -8,12 +8,15 @@ import json
 import math
 import os
 
+import sys
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))      # _attn_bwd_cases
 
 import hdiff_amd  # noqa: E402
 from hdiff_amd import autograd as A  # noqa: E402
@@ -192,21 +195,59 @@ def test_split_bf16_attention_backward_is_another_program_fp32_class_and_reprodu
     assert torch.isfinite(gx3).all()
     assert not torch.equal(gx3, g32), "the split-bf16 backward did not run"
     assert torch.equal(gx3, gx3_again), "not bitwise reproducible"
-    # float64 reference of two (sample, head) pairs, every position
+    # float64 reference of two (sample, head) pairs, every position: the forward's gate (rms <= 1.25x the fp32-input kernel's; the worst
+    # element of ONE pair against the fp32 kernel's worst is a ratio of two maxima over 131 072 values: 3x; all pairs: test below)
+    import _attn_bwd_cases as K
     for (b, h) in ((0, 0), (3, 5)):
-        sl = slice(h * d, (h + 1) * d)
-        Q = qkv[b, sl].double().t(); K = qkv[b, Cc + h * d:Cc + (h + 1) * d].double().t()
-        V = qkv[b, 2 * Cc + h * d:2 * Cc + (h + 1) * d].double().t(); dO = d_o[b, sl].double().t()
-        P = torch.softmax(Q @ K.t() / math.sqrt(d), dim=-1)
-        dP = dO @ V.t()
-        dS = P * (dP - (dO * (P @ V)).sum(-1, keepdim=True))
-        ref = {"dQ": (dS @ K / math.sqrt(d)).t(), "dK": (dS.t() @ Q / math.sqrt(d)).t(), "dV": (P.t() @ dO).t()}
+        ref = K.ref64(qkv, d_o, b, h, d, Cc)
         for i, name in enumerate(("dQ", "dK", "dV")):
             rows = slice(i * Cc + h * d, i * Cc + (h + 1) * d)
-            mag = ref[name].abs().max().item()
-            ex3 = (gx3[b, rows].double() - ref[name]).abs().max().item()
-            e32 = (g32[b, rows].double() - ref[name]).abs().max().item()
-            assert ex3 <= 3e-5 * mag and ex3 <= 4.0 * e32 + 1e-7 * mag, (name, b, h, ex3, e32, mag)
+            ex3, e32 = gx3[b, rows].double() - ref[name], g32[b, rows].double() - ref[name]
+            r3, r32 = ex3.pow(2).mean().sqrt().item(), e32.pow(2).mean().sqrt().item()
+            assert r3 <= 1.25 * r32, (name, b, h, r3, r32)
+            assert ex3.abs().max().item() <= 3.0 * e32.abs().max().item(), (name, b, h, ex3.abs().max().item(), e32.abs().max().item())
+
+
+@pytest.mark.parametrize("d", [16, 32])
+def test_attention_backward_fp16_pairs_error_class_every_pair(d):
+    """attention_bwd_h2.hip against float64, EVERY (sample, head) pair and every element, as the forward's tests do it: over all
+    pairs rms <= 1.25x and worst <= 2x the fp32-input kernel's; each pair on its own rms <= 1.25x (measured <= 1.03x,
+    tools/attn_bwd_error_ratio.py / profiles/r05_attention_bwd_error_ratio.txt) and worst <= 3x (measured <= 2.3x: a ratio of two
+    maxima over 32 768 values).  tests/test_gpu_mutation.py runs this test on the mutant libraries: it must turn red."""
+    import _attn_bwd_cases as K
+    from hdiff_amd import _capi
+    g = torch.Generator().manual_seed(7 + d)
+    qkv, d_o = K.make_case("plain", d, 2048, 2, 8, g)
+    st = K.error_stats(_capi.lib(), qkv.to(DEV), d_o.to(DEV), 8)
+    for name, s in st.items():
+        assert s["rms"][0] <= 1.25 * s["rms"][1], (name, s["rms"])
+        assert s["worst"][0] <= 2.0 * s["worst"][1], (name, s["worst"])
+        for (b, h, r2, r0, w2, w0, mag) in s["pair"]:
+            assert r2 <= 1.25 * r0 and w2 <= 3.0 * w0, (name, b, h, r2, r0, w2, w0)
+
+
+@pytest.mark.parametrize("d", [16, 32])
+@pytest.mark.parametrize("case", ["loud-dO-pixel", "wide-V", "peaked", "tiny-dO"])
+def test_attention_backward_fp16_pairs_ranges(case, d):
+    """What the fp16-pair backward adds to the bf16-triple one is RANGE: dO and V are scaled by ONE power of two per (sample, head).
+    One position of dO 1e4 x the rest (everything else 13 binades below the scale), V channels 2^30 apart, peaked rows
+    (|scores| ~ 40: dS lives on the cancellation dP - delta), dO x 1e-20 (the scale clamps at 2^64).  Over all pairs the error
+    against float64 stays in the fp32-input kernel's class (rms <= 1.25x, worst <= 2x; measured <= 0.97x / 1.25x) and below
+    2e-5 of the tensor's magnitude (measured <= 7e-6); a single pair's rms <= 4x (measured 2.3x where one loud row IS the pair's
+    rms).  What is NOT claimed: per-row relative error on peaked rows -- there dS is the difference of two nearly equal numbers
+    and the pairs' 2^-23 input rounding shows (dQ rows up to 50x the fp32 kernel's error relative to the ROW's own magnitude,
+    profiles/r05_attention_bwd_error_ratio.txt); the contract is fp32-class against the tensor, as in the forward."""
+    import _attn_bwd_cases as K
+    from hdiff_amd import _capi
+    g = torch.Generator().manual_seed(7 + d)
+    qkv, d_o = K.make_case(case, d, 2048, 2, 8, g)
+    st = K.error_stats(_capi.lib(), qkv.to(DEV), d_o.to(DEV), 8)
+    for name, s in st.items():
+        assert s["rms"][0] <= 1.25 * s["rms"][1], (case, name, s["rms"])
+        assert s["worst"][0] <= 2.0 * s["worst"][1], (case, name, s["worst"])
+        assert s["worst"][0] <= 2e-5 * s["mag"], (case, name, s["worst"], s["mag"])
+        for (b, h, r2, r0, w2, w0, mag) in s["pair"]:
+            assert r2 <= 4.0 * r0, (case, name, b, h, r2, r0)
 
 
 def test_linear_and_embedding_backward():

@@ -162,7 +162,21 @@ def test_c3_attention_backward_full_length(Cc, L, scale):
             err = (got.double() - ref).abs().max().item()
             mag = ref.abs().max().item()
             print(f"C={Cc} L={L} scale={scale} head {h} {name}: max err {err:.3e} (ref max {mag:.3e})")
-            assert err <= 5e-5 * mag + 1e-9, (name, h, err, mag)
+            # measured, both modes: <= 1.1e-6 of the magnitude at scale 1, <= 1.3e-5 at scale 3 (peaked rows: dS lives on a cancellation)
+            assert err <= (1e-5 if scale == 1.0 else 5e-5) * mag + 1e-9, (name, h, err, mag)
+    if Cc == 128 and scale == 1.0 and lib.hdiff_get_contraction_mode() == 1:
+        # the error CLASS at full length, one head, every element: rms <= 1.25x / worst <= 3x the fp32-input kernel's (a single pair)
+        _capi.check(lib.hdiff_set_contraction_mode(0))
+        try:
+            _, dq32 = bwd(d_o)
+        finally:
+            _capi.check(lib.hdiff_set_contraction_mode(1))
+        _, dq64, dk64, dv64 = _attention_bwd_f64_head(qkv[0], d_o[0], 0, heads)
+        for i, (name, ref) in enumerate((("dQ", dq64), ("dK", dk64), ("dV", dv64))):
+            rows = slice(i * Cc, i * Cc + d)
+            e2, e0 = dqkv[0, rows].double() - ref, dq32[0, rows].double() - ref
+            assert e2.pow(2).mean().sqrt().item() <= 1.25 * e0.pow(2).mean().sqrt().item(), (name, "rms")
+            assert e2.abs().max().item() <= 3.0 * e0.abs().max().item(), (name, "worst")
     # linear in dO (delta, dP and dS are all linear in it), and deterministic
     _, dqkv2 = bwd(d_o * -2.0)
     assert (dqkv2 + 2.0 * dqkv).abs().max().item() <= 1e-5 * dqkv.abs().max().item() * 2.0
