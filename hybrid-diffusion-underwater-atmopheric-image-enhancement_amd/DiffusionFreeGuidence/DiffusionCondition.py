@@ -24,7 +24,6 @@ import warnings
 from .. import _capi
 from .. import engine as E
 
-_WARNED_SAMPLER_GRAD = False
 
 __all__ = ["extract", "GaussianDiffusionTrainer", "GaussianDiffusionSampler"]
 
@@ -237,13 +236,18 @@ class GaussianDiffusionSampler(nn.Module):
         """``noise_by_step[time_step]`` injects the per-step z (parity tests); ``trajectory`` collects the pre-clip
         x_t after every step.  Both default to the reference behaviour."""
         x_T, labels = _gpu_input(x_T, "x_T"), _gpu_input(labels, "labels")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
+        if torch.is_grad_enabled():
             # The reference runs here too (DiffusionCondition.py:82-98) and records an autograd graph through all 2T model
             # evaluations, which nothing in its callers ever differentiates (TrainCondition.eval samples under no_grad).
-            # The loop here is an inference loop: it runs without a graph and hands back a detached tensor -- said once.
-            global _WARNED_SAMPLER_GRAD
-            if not _WARNED_SAMPLER_GRAD:
-                _WARNED_SAMPLER_GRAD = True
+            # The loop here is an inference loop: it runs without a graph and hands back a detached tensor.  A caller that
+            # asks for a gradient with respect to x_T clearly expects that graph: refused; enabled autograd with trainable
+            # parameters alone: said once per sampler instance (INTEGRATION.md section 3).
+            if x_T.requires_grad:
+                raise RuntimeError("GaussianDiffusionSampler.forward: x_T requires grad, but the denoising loop runs under "
+                                   "torch.no_grad() and cannot be differentiated (the reference would record a graph through all "
+                                   "2T model evaluations); detach x_T or call under torch.no_grad()")
+            if any(p.requires_grad for p in self.model.parameters()) and not getattr(self, "_warned_grad", False):
+                self._warned_grad = True
                 warnings.warn("GaussianDiffusionSampler.forward was called with autograd enabled: the denoising loop runs under "
                               "torch.no_grad() and returns a tensor without grad_fn (the reference would record a graph "
                               "through all 2T model evaluations)", RuntimeWarning, stacklevel=2)

@@ -245,8 +245,10 @@ class UNet(nn.Module):
 
     def invalidate_packed(self) -> None:
         """Force a repack on the next forward.  Needed only after a write that bypasses autograd's version counter
-        (``p.data.copy_``, ``dist.broadcast(p.data)``); ``p.copy_`` under ``no_grad``, optimizer steps and
-        ``load_state_dict`` are seen automatically, and ``GaussianDiffusionSampler.forward`` repacks on every call."""
+        (``p.data.copy_``, ``dist.broadcast(p.data)``) -- to a convolution weight OR to a GroupNorm weight / bias (the fp16-pair
+        convolutions stage their activations with a power of two computed from the GroupNorm parameters at pack time);
+        ``p.copy_`` under ``no_grad``, optimizer steps and ``load_state_dict`` are seen automatically, and
+        ``GaussianDiffusionSampler.forward`` repacks on every call."""
         self._packed_versions.clear()
 
     def plan_for(self, B: int, H: int, W: int, device) -> E.UNetPlan:

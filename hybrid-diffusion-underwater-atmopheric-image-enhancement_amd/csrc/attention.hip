@@ -529,24 +529,6 @@ __global__ __launch_bounds__(ATT_THREADS) void mha_flash_fwd_fast_kernel(const f
   }
 }
 
-int att_nq_override() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("HDIFF_ATT_NQ");   // dev knob: force the query tiles per wave (1, 4 or 8)
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
-int att_fast_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("HDIFF_ATT_FAST");   // dev knob: 0 disables the fixed-reference fast path
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
-
 template <int D, int NQ>
 void launch_v(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, int check,
               hipStream_t stream) {
@@ -566,16 +548,14 @@ int launch_d(const float* qkv, float* o, float* lse2, int B, int C, int heads, i
   } else {
     int nq = (L >= 512) ? 4 : 1;   // 4 query tiles per wave: 3 waves per SIMD at d_head 16, 2 at d_head 32 (8 tiles measured no faster)
     // d_head 32 on the fixed-reference kernel: 134 TFLOP/s against 120 on the running-max kernel (L = 16 384, batch 16)
-    if (att_nq_override() > 0) nq = att_nq_override();
     if (nq == 4 && contraction_mode() == HDIFF_CONTRACT_BF16X3 &&
-        (launch_mha_fwd_h2w(qkv, o, lse2, B, C, heads, L, qscale, ws, ws_bytes, stream) ||      // d_head 16 on 32x32x16 tiles (needs the workspace)
-         launch_mha_fwd_h2(qkv, o, lse2, B, C, heads, L, qscale, ws, ws_bytes, stream) ||       // P.V on fp16 pairs (needs the workspace)
-         launch_mha_fwd_x3p(qkv, o, lse2, B, C, heads, L, qscale, ws, ws_bytes, stream) ||      // pre-split operands (needs the workspace)
-         launch_mha_fwd_x3(qkv, nullptr, o, lse2, B, C, heads, L, qscale, stream))) {
+        (launch_mha_fwd_h2(qkv, o, lse2, B, C, heads, L, qscale, ws, ws_bytes, stream) ||       // d_head 16, fp16 pairs (needs the workspace)
+         launch_mha_fwd_x3p(qkv, o, lse2, B, C, heads, L, qscale, ws, ws_bytes, stream) ||      // d_head 32, fp16 pairs (needs the workspace)
+         launch_mha_fwd_x3(qkv, o, lse2, B, C, heads, L, qscale, stream))) {                    // bf16 triples split in the loop
       // split-bf16 kernel (attention_x3.hip), same fixed-reference protocol: overflow-proof fp32 kernel in check mode behind it
       static const bool skip_check = getenv("HDIFF_NO_CHECK_PASS") != nullptr;      // dev knob: look at the poisoned rows
       if (!skip_check) launch_v<D, 4>(qkv, o, lse2, B, C, heads, L, qscale, 1, stream);
-    } else if (nq == 4 && L % KT == 0 && att_fast_enabled()) {
+    } else if (nq == 4 && L % KT == 0) {
       // fixed-reference fast kernel, then the overflow-proof kernel in check mode (exits at once unless flagged)
       dim3 grid(cdiv(L, 256), heads, B);
       hipLaunchKernelGGL((mha_flash_fwd_fast_kernel<D, 4>), grid, dim3(ATT_THREADS), 0, stream, qkv, o, lse2, C, L, qscale);

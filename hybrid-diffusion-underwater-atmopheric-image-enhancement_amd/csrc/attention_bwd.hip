@@ -485,12 +485,6 @@ struct BwdGeom { int nk, nkb_total, per, nsplit; };
 static BwdGeom bwd_geometry(int B, int heads, int L, int D) {
   BwdGeom g;
   g.nk = (L <= 4096 || D >= 48) ? 1 : (D > 16 ? 2 : 4);   // short sequences: 64-key blocks for enough workgroups
-  { // dev knob: a SMALLER key block.  Only the widths the launch dispatches on (1, 2, 4) are accepted -- any other value
-    // would size the geometry for a kernel that is never launched -- and the raggedness rule below applies to the result.
-    static const char* e = getenv("HDIFF_BWD_NK");
-    const int v = e ? atoi(e) : 0;
-    if ((v == 1 || v == 2 || v == 4) && v <= g.nk) g.nk = v;
-  }
   if (L % (64 * g.nk) != 0) g.nk = 1;                      // ragged sequences: the generic (bounds-checked) kernel, 64-key blocks
   const int KB = 64 * g.nk;
   g.nkb_total = cdiv(L, KB);
@@ -523,9 +517,7 @@ int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* 
       const int total = B * heads * L;
       (void)hipGetLastError();
       hipLaunchKernelGGL(mha_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, o, d_o, delta, C, D, L, total);
-      static const char* pv = getenv("HDIFF_PV");          // dev knob: "bf16x3" keeps the bf16-triple kernels of round 3
-      if (pv && strcmp(pv, "bf16x3") == 0) launch_mha_bwd_x3(qkv, d_o, lse2, delta, dqkv, ws, B, C, heads, L, stream);
-      else launch_mha_bwd_h2(qkv, d_o, lse2, delta, dqkv, ws, B, C, heads, L, stream);
+      launch_mha_bwd_h2(qkv, d_o, lse2, delta, dqkv, ws, B, C, heads, L, stream);
       HDIFF_CHECK_LAUNCH("mha_bwd (split-bf16) kernels");
       return HDIFF_OK;
     }

@@ -1,5 +1,6 @@
-// Backward of the flash self-attention core at d_head 16 and 32, round 4: the split-operand kernel of attention_bwd_x3.hip
-// with everything that touches P = exp2(S - lse) or the pair (dO, V) moved from bf16 triples to fp16 PAIRS
+// Backward of the flash self-attention core at d_head 16 and 32 in the split-operand mode.  Round 3 built it on bf16 triples
+// throughout (attention_bwd_x3.hip, retired in round 5: git show 6a5a4b1 has it); round 4 moved everything that touches
+// P = exp2(S - lse) or the pair (dO, V) to fp16 PAIRS
 // (attention_h2.hip has the argument and the instructions: v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16, 1.5 per value against 5.5).
 // Same contract, layouts and dQ slab protocol (reference: autograd through nn.MultiheadAttention, ModelCondition.py:189,
 // 204-208, TrainCondition.py:60): bitwise reproducible.
@@ -591,7 +592,6 @@ H2Geom h2_geometry(int B, int heads, int L, int D) {
     int more = 16 < cap ? 16 : cap;
     if (more > want) want = more;
   }
-  { static const char* e = getenv("HDIFF_BWD_X3_WANT"); const int v = e ? atoi(e) : 0; if (v > want) want = v; }   // dev knob
   if (want > g.nkb_total) want = g.nkb_total;
   if (want < 1) want = 1;
   g.per = cdiv(g.nkb_total, want);
@@ -603,8 +603,39 @@ H2Geom h2_geometry(int B, int heads, int L, int D) {
 
 namespace hdiff {
 
-// Workspace: that of the bf16-triple kernel (slabs + piece tensors: the V and dO slots hold two pieces instead of three)
-// plus the B * heads * 2 maxima, which mha_bwd_x3_workspace_floats accounts for.
+// Upper bound on the dQ partial slabs (it sets how many key ranges a (sample, head) pair is cut into at large batches): 16 GiB, or
+// HDIFF_BWD_SLAB_GIB gibibytes (1 ... 256; a deployment setting, read once per process; tests/test_gpu_backward.py).
+long long mha_bwd_slab_cap_bytes() {
+  static const long long cap = [] {
+    const char* e = getenv("HDIFF_BWD_SLAB_GIB");
+    long long g = e ? atoll(e) : 16;
+    if (g < 1) g = 1;
+    if (g > 256) g = 256;
+    return g << 30;
+  }();
+  return cap;
+}
+
+// shapes the kernel covers: at least one 128-key block per CU -- below that (one sample at L <= 1024) the split pass and the
+// slab reduce cost more than the matrix core gains (56 vs 47 us at B = 1, L = 1024; 0.62 vs 0.94 ms at B = 4, L = 4096)
+bool mha_bwd_x3_shape_ok(int B, int C, int heads, int L) {
+  const int D = C / heads;
+  return C % heads == 0 && (D == 16 || D == 32) && L % 256 == 0 && L >= 512 && (int64_t)B * heads * (L / KB) >= 256;
+}
+bool mha_bwd_x3_applicable(int B, int C, int heads, int L) {
+  return contraction_mode() == HDIFF_CONTRACT_BF16X3 && mha_bwd_x3_shape_ok(B, C, heads, L);
+}
+
+// slabs (tile-major, one per key range: even a single range goes through the reduce kernel, which restores the [C][L] layout)
+// followed by the piece tensors (fifteen 2-byte piece slots per element: the layout round 3's bf16-triple kernel introduced; the V
+// and dO tensors fill two of their three) and the B * heads * 2 tensor maxima, in floats
+int64_t mha_bwd_x3_workspace_floats(int B, int C, int heads, int L) {
+  const H2Geom g = h2_geometry(B, heads, L, C / heads);
+  const int64_t pieces_bytes = (int64_t)B * C * L * (T_COUNT * 3) * 2;
+  return (int64_t)g.nsplit * B * C * L + (pieces_bytes + 3) / 4 + 4 + (int64_t)B * heads * 2 + 4;
+}
+
+// delta has been computed by the caller (mha_delta_kernel)
 void launch_mha_bwd_h2(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, float* ws,
                        int B, int C, int heads, int L, hipStream_t stream) {
   const int D = C / heads;

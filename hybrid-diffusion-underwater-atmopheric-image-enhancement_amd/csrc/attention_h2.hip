@@ -678,15 +678,6 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
 }  // namespace
 
 namespace hdiff {
-bool mha_fwd_h2_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("HDIFF_PV");     // dev knob: "bf16x3" keeps the bf16-triple P.V kernels of round 3
-    v = (e && strcmp(e, "bf16x3") == 0) ? 0 : 1;
-  }
-  return v != 0;
-}
-
 // V of qkv as two fp16 pieces of V 2^s (s per channel row) + the D factors 2^-s, into the V region of the pre-split workspace
 void launch_v_split_h2(const float* qkv, void* ws, int B, int C, int heads, int L, hipStream_t stream) {
   if (C / heads == 16) hipLaunchKernelGGL((v_split_h2_kernel<16>), dim3(C, B), dim3(THREADS), 0, stream, qkv, (__bf16*)ws, C, L, 1.0f);
@@ -710,7 +701,7 @@ void launch_qk_split_h2(const float* qkv, void* ws, int B, int C, int heads, int
 bool launch_mha_fwd_h2(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
                        int64_t ws_bytes, hipStream_t stream) {
   const int64_t need = mha_fwd_x3p_workspace(B, C, heads, L);
-  if (!mha_fwd_h2_enabled() || need == 0 || ws == nullptr || ws_bytes < need) return false;
+  if (need == 0 || ws == nullptr || ws_bytes < need) return false;
   const int D = C / heads;
   if (D != 16) return false;
   launch_qk_split_h2(qkv, ws, B, C, heads, L, qscale, stream);

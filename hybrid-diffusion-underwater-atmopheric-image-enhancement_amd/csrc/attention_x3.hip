@@ -80,17 +80,14 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 __device__ constexpr int TERM_A[6] = {0, 1, 0, 2, 1, 0};
 __device__ constexpr int TERM_B[6] = {0, 0, 1, 0, 1, 2};
 
-// (Tried on top of PRE and removed: a schedule pipelined ACROSS key tiles -- QK^T of the next tile's first query tile in
-// the last stage, P.V of the previous tile's last one in the first, three LDS buffers, one barrier -- so that every stage
-// has 24 MFMAs beside its exp / split stream.  The compiler clumps the MFMAs of such a body whatever the
-// sched_group_barrier pattern (256 registers): 171-173 TFLOP/s-equivalent against 179 for this per-tile schedule, same box.)
-// PRE: Q, K, V arrive already split into bf16 pieces (the workspace written by qkv_split3_kernel, attention_x3p.hip:
-// per (sample, head) Qs[3][L][D] pre-scaled, Ks[3][L][D], Vs[3][D][L]) -- the staging threads then only copy, and the ~10 %
-// of the loop's vector instructions that re-split K / V in every one of the 256 workgroups of a (head, sample) are gone.
-template <int D, int NQ, bool PRE>
+// Round 5: this kernel serves the calls WITHOUT a workspace (hdiff_mha_flash_fwd; the engine always passes one, and then the
+// fp16-pair kernels of attention_h2.hip / attention_x3p.hip run): fp32 operands in, split into bf16 triples by the staging threads
+// of every workgroup.  Rounds 3 / 4 also fed it pre-split operands from the workspace (PRE; git show 6a5a4b1 has that form).
+template <int D, int NQ>
 __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3_kernel(const float* __restrict__ qkv, const __bf16* __restrict__ ws,
                                                                       float* __restrict__ out, float* __restrict__ lse2, int C,
                                                                       int L, float qscale) {
+  (void)ws;
   static_assert(D == 16 || D == 32, "head dim");
   constexpr int TPM = 32 / D;              // terms per QK^T MFMA
   constexpr int NQK = 6 / TPM;             // QK^T MFMAs per 16x16 score tile
@@ -122,25 +119,18 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3_kernel(const floa
   const bool hi = (TPM == 2) && (g >> 1);
 
   // Q operands: pre-scaled (exp2 domain), split once
-  const size_t piece_n = (size_t)L * D;
-  const __bf16* wsq = PRE ? ws + ((size_t)b * gridDim.y + head) * 9 * piece_n : nullptr;
   u32x4 qop[NQ][NQK];
 #pragma unroll
   for (int qt = 0; qt < NQ; ++qt) {
     const int q = qblk0 + qt * 16 + i16;
     u32x4 piece[3];
-    if constexpr (PRE) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) piece[p] = *reinterpret_cast<const u32x4*>(wsq + p * piece_n + (size_t)q * D + doff);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a = (q < L) ? qbase[(size_t)(doff + 2 * j) * L + q] * qscale : 0.f;
-        const float c = (q < L) ? qbase[(size_t)(doff + 2 * j + 1) * L + q] * qscale : 0.f;
-        unsigned h0, h1, h2;
-        split3(a, c, h0, h1, h2);
-        piece[0][j] = h0; piece[1][j] = h1; piece[2][j] = h2;
-      }
+    for (int j = 0; j < 4; ++j) {
+      const float a = (q < L) ? qbase[(size_t)(doff + 2 * j) * L + q] * qscale : 0.f;
+      const float c = (q < L) ? qbase[(size_t)(doff + 2 * j + 1) * L + q] * qscale : 0.f;
+      unsigned h0, h1, h2;
+      split3(a, c, h0, h1, h2);
+      piece[0][j] = h0; piece[1][j] = h1; piece[2][j] = h2;
     }
 #pragma unroll
     for (int j = 0; j < NQK; ++j) {
@@ -157,78 +147,37 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3_kernel(const floa
   }
   const int vaddr = i16 * VROWB + 8 * g;
 
-  // staging.  fp32 source: K thread = (key, group of DK d), V thread = (d, 4 keys), split while storing.  Pre-split source:
-  // chunk c = i * 256 + tid of the tile's 16-byte chunks (K pieces, then V pieces), copied as they are.
+  // staging: K thread = (key, group of DK d), V thread = (d, 4 keys), split into bf16 triples while storing
   const int skey = tid & 63, sdg = tid >> 6;
   const int sd = tid >> 4, sseg = tid & 15;
-  float kst[PRE ? 1 : DK];
-  f32x4 vst[PRE ? 1 : NVL];
-  constexpr int NKC = 3 * KT * D / 8, NVC = 3 * D * 8, NLD = (NKC + NVC) / THREADS;
-  static_assert((NKC + NVC) % THREADS == 0, "staging geometry");
-  const unsigned char* gsrc[NLD];
-  int lds_off[NLD], gstep[NLD];
-  u32x4 stage[PRE ? NLD : 1];
-  if constexpr (PRE) {
-    const __bf16* ksp = wsq + 3 * piece_n;
-    const __bf16* vsp = wsq + 6 * piece_n;
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int c = i * THREADS + tid;
-      if (c < NKC) {
-        const int p = c / (KT * D / 8), rem = c - p * (KT * D / 8);
-        gsrc[i] = reinterpret_cast<const unsigned char*>(ksp + p * piece_n) + (size_t)rem * 16;
-        lds_off[i] = p * KPART + rem * 16;                       // rows of D * 2 bytes, no padding: the tile is one block
-        gstep[i] = KT * D * 2;
-      } else {
-        const int cv = c - NKC;
-        const int p = cv / (D * 8), rem = cv - p * (D * 8);
-        const int d = rem >> 3, seg = rem & 7;
-        gsrc[i] = reinterpret_cast<const unsigned char*>(vsp + p * piece_n + (size_t)d * L) + seg * 16;
-        lds_off[i] = VBASE + p * VPART + d * VROWB + seg * 16;
-        gstep[i] = KT * 2;
-      }
-    }
-  }
+  float kst[DK];
+  f32x4 vst[NVL];
   auto stage_load = [&](int t) {
-    if constexpr (PRE) {
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) stage[i] = *reinterpret_cast<const u32x4*>(gsrc[i] + (size_t)t * gstep[i]);
-    } else {
+    for (int j = 0; j < DK; ++j) kst[j] = kbase[(size_t)(sdg * DK + j) * L + t * KT + skey];
 #pragma unroll
-      for (int j = 0; j < DK; ++j) kst[j] = kbase[(size_t)(sdg * DK + j) * L + t * KT + skey];
-#pragma unroll
-      for (int i = 0; i < NVL; ++i)
-        vst[i] = *reinterpret_cast<const f32x4*>(vbase + (size_t)(sd + 16 * i) * L + t * KT + 4 * sseg);
-    }
+    for (int i = 0; i < NVL; ++i)
+      vst[i] = *reinterpret_cast<const f32x4*>(vbase + (size_t)(sd + 16 * i) * L + t * KT + 4 * sseg);
   };
   auto stage_store = [&](int buf) {
-    if constexpr (PRE) {
+    unsigned kp[3][DK / 2];
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) {       // two 8-byte stores for K and V chunks alike: no per-thread branch
-        unsigned char* dst = &smem[buf][lds_off[i]];
-        *reinterpret_cast<u32x2*>(dst) = u32x2{stage[i][0], stage[i][1]};
-        *reinterpret_cast<u32x2*>(dst + 8) = u32x2{stage[i][2], stage[i][3]};
-      }
-    } else {
-      unsigned kp[3][DK / 2];
+    for (int j = 0; j < DK / 2; ++j) split3(kst[2 * j], kst[2 * j + 1], kp[0][j], kp[1][j], kp[2][j]);
 #pragma unroll
-      for (int j = 0; j < DK / 2; ++j) split3(kst[2 * j], kst[2 * j + 1], kp[0][j], kp[1][j], kp[2][j]);
+    for (int p = 0; p < 3; ++p) {
+      unsigned char* dst = &smem[buf][p * KPART + skey * KROWB + sdg * DK * 2];
+      if (DK == 4) *reinterpret_cast<u32x2*>(dst) = u32x2{kp[p][0], kp[p][1]};
+      else *reinterpret_cast<u32x4*>(dst) = u32x4{kp[p][0], kp[p][1], kp[p][2 % (DK / 2)], kp[p][3 % (DK / 2)]};
+    }
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        unsigned char* dst = &smem[buf][p * KPART + skey * KROWB + sdg * DK * 2];
-        if (DK == 4) *reinterpret_cast<u32x2*>(dst) = u32x2{kp[p][0], kp[p][1]};
-        else *reinterpret_cast<u32x4*>(dst) = u32x4{kp[p][0], kp[p][1], kp[p][2 % (DK / 2)], kp[p][3 % (DK / 2)]};
-      }
-#pragma unroll
-      for (int i = 0; i < NVL; ++i) {
-        unsigned a0, a1, a2, b0, b1, b2;
-        split3(vst[i][0], vst[i][1], a0, a1, a2);
-        split3(vst[i][2], vst[i][3], b0, b1, b2);
-        unsigned char* dst = &smem[buf][VBASE + (sd + 16 * i) * VROWB + sseg * 8];
-        *reinterpret_cast<u32x2*>(dst) = u32x2{a0, b0};
-        *reinterpret_cast<u32x2*>(dst + VPART) = u32x2{a1, b1};
-        *reinterpret_cast<u32x2*>(dst + 2 * VPART) = u32x2{a2, b2};
-      }
+    for (int i = 0; i < NVL; ++i) {
+      unsigned a0, a1, a2, b0, b1, b2;
+      split3(vst[i][0], vst[i][1], a0, a1, a2);
+      split3(vst[i][2], vst[i][3], b0, b1, b2);
+      unsigned char* dst = &smem[buf][VBASE + (sd + 16 * i) * VROWB + sseg * 8];
+      *reinterpret_cast<u32x2*>(dst) = u32x2{a0, b0};
+      *reinterpret_cast<u32x2*>(dst + VPART) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(dst + 2 * VPART) = u32x2{a2, b2};
     }
   };
 
@@ -386,23 +335,16 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_x3_kernel(const floa
 
 namespace hdiff {
 
-// Launches the split-bf16 kernel for (d_head, L) it supports; returns false if this shape is not covered.  `ws` != NULL:
-// the operands were already split into the workspace (launch_qkv_split3, attention_x3p.hip).
-bool launch_mha_fwd_x3(const float* qkv, const void* ws, float* o, float* lse2, int B, int C, int heads, int L, float qscale,
-                       hipStream_t stream) {
+// Launches the split-bf16 kernel for (d_head, L) it supports; returns false if this shape is not covered.
+bool launch_mha_fwd_x3(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, hipStream_t stream) {
   const int D = C / heads;
   if (L % KT != 0 || L < 512) return false;
-  const __bf16* w = (const __bf16*)ws;
   if (D == 16) {
-    dim3 grid(cdiv(L, 256), heads, B);
-    if (w) hipLaunchKernelGGL((mha_flash_fwd_x3_kernel<16, 4, true>), grid, dim3(THREADS), 0, stream, qkv, w, o, lse2, C, L, qscale);
-    else hipLaunchKernelGGL((mha_flash_fwd_x3_kernel<16, 4, false>), grid, dim3(THREADS), 0, stream, qkv, w, o, lse2, C, L, qscale);
+    hipLaunchKernelGGL((mha_flash_fwd_x3_kernel<16, 4>), dim3(cdiv(L, 256), heads, B), dim3(THREADS), 0, stream, qkv, nullptr, o, lse2, C, L, qscale);
     return true;
   }
   if (D == 32) {
-    dim3 grid(cdiv(L, 128), heads, B);
-    if (w) hipLaunchKernelGGL((mha_flash_fwd_x3_kernel<32, 2, true>), grid, dim3(THREADS), 0, stream, qkv, w, o, lse2, C, L, qscale);
-    else hipLaunchKernelGGL((mha_flash_fwd_x3_kernel<32, 2, false>), grid, dim3(THREADS), 0, stream, qkv, w, o, lse2, C, L, qscale);
+    hipLaunchKernelGGL((mha_flash_fwd_x3_kernel<32, 2>), dim3(cdiv(L, 128), heads, B), dim3(THREADS), 0, stream, qkv, nullptr, o, lse2, C, L, qscale);
     return true;
   }
   return false;

@@ -134,37 +134,24 @@ int contraction_mode();   // HDIFF_CONTRACT_*
 #define HDIFF_MUTANT 0
 #endif
 
-// Upper bound on the dQ partial slabs of the split-operand attention backward (it sets how many key ranges a (sample, head) pair
-// is cut into at large batches): 16 GiB, or HDIFF_BWD_SLAB_GIB gibibytes (1 ... 256; read once per process).  The workspace
-// query and both backward kernels use this one function, so they agree.
-long long mha_bwd_slab_cap_bytes();
-// attention_bwd_x3.hip: the attention backward at d_head 16 in the split-bf16 formulation (dispatched from attention_bwd.hip)
+// attention_bwd_h2.hip: the attention backward at d_head 16 / 32 in the split-operand mode (dispatched from attention_bwd.hip)
+long long mha_bwd_slab_cap_bytes();                          // upper bound on the dQ partial slabs (HDIFF_BWD_SLAB_GIB)
 bool mha_bwd_x3_shape_ok(int B, int C, int heads, int L);     // the shape alone (mode-independent)
 bool mha_bwd_x3_applicable(int B, int C, int heads, int L);   // shape AND the bf16x3 contraction mode
-int64_t mha_bwd_x3_workspace_floats(int B, int C, int heads, int L);   // dQ slabs + piece tensors
-void launch_mha_bwd_x3(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, float* ws, int B,
-                       int C, int heads, int L, hipStream_t stream);
-// attention_bwd_h2.hip: the same backward with P and the (dO, V) pair on fp16 pairs; shapes, workspace and slab geometry
-// are those of the bf16-triple kernel above
+int64_t mha_bwd_x3_workspace_floats(int B, int C, int heads, int L);   // dQ slabs + piece tensors + maxima
 void launch_mha_bwd_h2(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, float* ws, int B,
                        int C, int heads, int L, hipStream_t stream);
-// attention_x3.hip: returns false when the shape is not covered (caller falls back to the fp32 kernels)
-// attention_x3p.hip: the same contraction on operands split ONCE into a workspace (0 bytes = shape not covered)
+// Attention forward in the split-operand mode.  attention_x3p.hip: d_head 32 on operands split ONCE into a workspace (fp16 pairs;
+// 0 bytes = shape not covered); attention_h2.hip: d_head 16 likewise, and the split passes of both; attention_x3.hip: the kernel that
+// splits in its loop (bf16 triples), for calls without a workspace.  Each returns false when the shape is not covered / no workspace.
 int64_t mha_fwd_x3p_workspace(int B, int C, int heads, int L);
+int64_t mha_fwd_h2_tail_bytes(int B, int C);      // bytes behind the pairs of the workspace (Q / K row maxima)
 bool launch_mha_fwd_x3p(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
                         int64_t ws_bytes, hipStream_t stream);
-void launch_qk_split3(const float* qkv, void* ws, int B, int C, int heads, int L, float qscale, hipStream_t stream);
-// attention_h2.hip: P.V on fp16 pairs (Q K^T on the bf16 triples of the same workspace); false = shape not covered / no workspace
 bool launch_mha_fwd_h2(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
                        int64_t ws_bytes, hipStream_t stream);
-// attention_h2w.hip: the same formulation at d_head 16 on 32x32x16 tiles, operands in MFMA order (its own workspace layout)
-bool launch_mha_fwd_h2w(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, void* ws,
-                        int64_t ws_bytes, hipStream_t stream);
-int64_t mha_fwd_h2_tail_bytes(int B, int C);      // bytes behind the pairs of the workspace (Q / K row maxima of the d_head 16 kernel)
-bool mha_fwd_h2_enabled();          // dev knob HDIFF_PV=bf16x3 keeps the bf16-triple P.V kernels
 void launch_qk_split_h2(const float* qkv, void* ws, int B, int C, int heads, int L, float qscale, hipStream_t stream);   // Q, K as fp16 score operands
-void launch_v_split_h2(const float* qkv, void* ws, int B, int C, int heads, int L, hipStream_t stream);   // V as fp16 pairs, d_head 16 / 32
-bool launch_mha_fwd_x3(const float* qkv, const void* ws /* pre-split operands or NULL */, float* o, float* lse2, int B, int C,
-                       int heads, int L, float qscale, hipStream_t stream);
+void launch_v_split_h2(const float* qkv, void* ws, int B, int C, int heads, int L, hipStream_t stream);                  // V as fp16 pairs, d_head 16 / 32
+bool launch_mha_fwd_x3(const float* qkv, float* o, float* lse2, int B, int C, int heads, int L, float qscale, hipStream_t stream);
 
 }  // namespace hdiff

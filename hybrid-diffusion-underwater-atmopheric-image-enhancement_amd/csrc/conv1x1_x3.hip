@@ -259,9 +259,7 @@ namespace hdiff {
 
 void launch_conv1x1_x3(const Conv1x1X3K& k, int B, hipStream_t stream) {
   dim3 grid(cdiv(k.Cout, 64), (unsigned)(k.HW / 256), B);
-  static const char* e = getenv("HDIFF_CONV1X1_WLDS");        // dev knob (A/B): 0 = every wave fetches its own weight operands from L2
-  if (e && atoi(e) == 0) hipLaunchKernelGGL(conv1x1_x3_kernel<false>, grid, dim3(THREADS), 0, stream, k);
-  else hipLaunchKernelGGL(conv1x1_x3_kernel<true>, grid, dim3(THREADS), 0, stream, k);
+  hipLaunchKernelGGL(conv1x1_x3_kernel<true>, grid, dim3(THREADS), 0, stream, k);      // <false> (every wave fetches its own weight operands from L2): tools builds
 }
 
 }  // namespace hdiff

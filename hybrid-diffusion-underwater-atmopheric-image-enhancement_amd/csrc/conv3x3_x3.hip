@@ -500,9 +500,7 @@ void launch_conv3x3_x3(const ConvX3K& k, int B, hipStream_t stream) {
   const size_t dyn = (size_t)2 * k.Cin * sizeof(float);
   const bool outmap = !(k.out_sy == 1 && k.out_oy == 0 && k.out_sx == 1 && k.out_ox == 0 && k.OH == k.H && k.OW == k.W);
   if (k.act_scale != nullptr) {            // fp16 pairs: the plain 3x3 conv behind GroupNorm + Swish (the dispatcher checked the shape)
-    static const char* e = getenv("HDIFF_CONV_OCC");      // dev knob: 3 = the build held to 168 registers (three workgroups per CU)
-    if (e && atoi(e) == 3) hipLaunchKernelGGL((conv3x3_x3_kernel<9, false, true, 3>), grid, dim3(THREADS), dyn, stream, k);
-    else hipLaunchKernelGGL((conv3x3_x3_kernel<9, false, true>), grid, dim3(THREADS), dyn, stream, k);
+    hipLaunchKernelGGL((conv3x3_x3_kernel<9, false, true>), grid, dim3(THREADS), dyn, stream, k);
     return;
   }
   if (k.ntaps == 9 && !outmap) hipLaunchKernelGGL((conv3x3_x3_kernel<9, false, false>), grid, dim3(THREADS), dyn, stream, k);

@@ -639,8 +639,6 @@ namespace {
 // GroupNorm + Swish prologue (or an activation tensor made from it), bounded by the GroupNorm weights (act_scale from
 // hdiff_gn_act_scale, weights from hdiff_pack_conv_weight_h2).
 bool is_h2_conv_shape(const hdiff_conv_desc* d, bool same) {
-  static const char* e = getenv("HDIFF_CONV");       // dev knob: "bf16x3" keeps the bf16-triple kernel everywhere
-  if (e && strcmp(e, "bf16x3") == 0) return false;
   return same && d->ntaps == 9 && d->wp_h2 != nullptr && d->act_scale != nullptr;
 }
 bool is_x3_conv(const hdiff_conv_desc* d) {
@@ -681,10 +679,8 @@ bool is_direct_1x1(const hdiff_conv_desc* d) {
          d->C0 % 2 == 0 && (long)(d->C0 + d->C1) * d->H * d->W < (1L << 30) && d->CinPad * d->CoutPad < (1 << 30);
 }
 // ... and in the split-bf16 mode, with a one-tap bf16-triple pack (hdiff_pack_conv_weight_x3_taps, ntaps = 1) and 16-channel-aligned
-// inputs, the same GEMM runs on the bf16 MFMA (conv1x1_x3.hip).  Dev knob HDIFF_CONV1X1=f32 keeps the fp32-input kernel.
+// inputs, the same GEMM runs on the bf16 MFMA (conv1x1_x3.hip).
 bool is_x3_1x1(const hdiff_conv_desc* d) {
-  static const char* e = getenv("HDIFF_CONV1X1");
-  if (e && strcmp(e, "f32") == 0) return false;
   const int Cin = d->C0 + d->C1;
   return d->wp_x3 != nullptr && hdiff::contraction_mode() == HDIFF_CONTRACT_BF16X3 && Cin % 16 == 0 &&
          (d->C1 == 0 || d->C0 % 16 == 0) && ((long)d->H * d->W) % 256 == 0 && d->CoutPad % 64 == 0;

@@ -271,14 +271,12 @@ int ceil_log2w(int v) {
 
 extern "C" int hdiff_conv2d_wgrad_workspace(const hdiff_conv_wgrad_desc* d, int* nsplit_out, int64_t* floats_out) {
   HDIFF_CHECK_ARG(d && nsplit_out && floats_out, "conv2d_wgrad_workspace: null pointer");
-  const bool specialised = getenv("HDIFF_WGRAD_GENERIC") == nullptr;   // the same dev switch as in hdiff_conv2d_wgrad: the
-                                                                       // A/B run of the generic kernel gets ITS split
-  if (specialised && wgrad1x1_applicable(d)) {
+  if (wgrad1x1_applicable(d)) {
     *nsplit_out = wgrad1x1_nsplit(d);
     *floats_out = (int64_t)*nsplit_out * d->ntaps * d->CinPad * d->CoutPad;
     return HDIFF_OK;
   }
-  if (specialised && wgrad3x3_applicable(d)) {
+  if (wgrad3x3_applicable(d)) {
     *nsplit_out = wgrad3x3_nsplit(d);
     *floats_out = (int64_t)*nsplit_out * d->ntaps * d->CinPad * d->CoutPad;
     return HDIFF_OK;
@@ -306,10 +304,8 @@ extern "C" int hdiff_conv2d_wgrad(const hdiff_conv_wgrad_desc* d, float* dwp, in
   HDIFF_CHECK_ARG(d->B > 0 && d->VH > 0 && d->VW > 0 && d->in_stride >= 1 && d->in_stride <= 2 && nsplit >= 1,
                   "conv2d_wgrad: bad geometry");
   HDIFF_CHECK_ARG((d->gn_scale == nullptr) == (d->gn_shift == nullptr), "conv2d_wgrad: gn_scale/gn_shift must come together");
-  if (getenv("HDIFF_WGRAD_GENERIC") == nullptr) {     // env: dev switch for A/B runs against the generic kernel
-    if (wgrad1x1_applicable(d)) return launch_wgrad1x1(d, dwp, nsplit, (hipStream_t)stream);
-    if (wgrad3x3_applicable(d)) return launch_wgrad3x3(d, dwp, nsplit, (hipStream_t)stream);
-  }
+  if (wgrad1x1_applicable(d)) return launch_wgrad1x1(d, dwp, nsplit, (hipStream_t)stream);
+  if (wgrad3x3_applicable(d)) return launch_wgrad3x3(d, dwp, nsplit, (hipStream_t)stream);
 
   WgradK k{};
   k.x0 = d->x0; k.x1 = d->x1; k.C0 = d->C0; k.C1 = d->C1; k.Cin = d->C0 + d->C1; k.H = d->H; k.W = d->W;

@@ -28,8 +28,6 @@ import torch.nn.functional as F
 from .. import _capi
 from .. import engine as E
 
-_WARNED_SAMPLER_GRAD = False
-
 __all__ = ["extract", "GaussianDiffusionSampler"]
 
 
@@ -143,11 +141,13 @@ class GaussianDiffusionSampler(nn.Module):
         the ancestral loop, in call order); by default they come from torch's generator exactly where the reference draws
         them.  ``trajectory`` collects the pre-clip y_t after every step.  Called with autograd enabled (the reference would
         record a graph through every model evaluation, diffusion/Diffusion.py:217-269) the loop still runs without one and
-        returns a detached tensor, with one RuntimeWarning per process."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
-            global _WARNED_SAMPLER_GRAD
-            if not _WARNED_SAMPLER_GRAD:
-                _WARNED_SAMPLER_GRAD = True
+        returns a detached tensor, with one RuntimeWarning per sampler instance; an input that requires grad is refused."""
+        if torch.is_grad_enabled():
+            if input_image.requires_grad or (y_T is not None and torch.is_tensor(y_T) and y_T.requires_grad):
+                raise RuntimeError("GaussianDiffusionSampler.forward: an input requires grad, but the sampling loop runs under "
+                                   "torch.no_grad() and cannot be differentiated; detach it or call under torch.no_grad()")
+            if any(p.requires_grad for p in self.model.parameters()) and not getattr(self, "_warned_grad", False):
+                self._warned_grad = True
                 warnings.warn("GaussianDiffusionSampler.forward was called with autograd enabled: the sampling loop runs under "
                               "torch.no_grad() and returns a tensor without grad_fn", RuntimeWarning, stacklevel=2)
         with torch.no_grad():

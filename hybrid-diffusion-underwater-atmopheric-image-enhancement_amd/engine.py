@@ -104,7 +104,15 @@ class PackedConv:
         GroupNorm(gamma, beta) + Swish over groups of ``group_elems`` elements, times ``gain`` (1 / keep behind a dropout):
         that output is bounded by sqrt(n - 1) max|gamma| + max|beta|, which fixes the power of two the activations are staged
         with (hdiff_gn_act_scale, evaluated at pack time like the weights)."""
-        if self.ntaps == 9 and self.cin % 16 == 0 and tuple(w.shape[2:]) == (3, 3) and self.wp2 is None:
+        ident = (gamma.data_ptr(), beta.data_ptr(), int(group_elems), float(gain))
+        if self.wp2 is not None:
+            # one pack = one staging scale: a second conv behind another GroupNorm (or another gain) must not inherit it silently
+            have = (self._h2_gn[0].data_ptr(), self._h2_gn[1].data_ptr(), self._h2_gn[2], self._h2_gn[3])
+            if have != ident:
+                raise RuntimeError("PackedConv.enable_h2: this pack already stages activations for another GroupNorm / gain; "
+                                   "use one PackedConv per (convolution, GroupNorm) pair")
+            return
+        if self.ntaps == 9 and self.cin % 16 == 0 and tuple(w.shape[2:]) == (3, 3):
             words = C.c_int64(0)
             _capi.check(_capi.lib().hdiff_pack_conv_weight_h2_words(self.cout, self.cin, self.cout_pad, C.byref(words)),
                         "pack_conv_weight_h2_words")
@@ -289,7 +297,8 @@ class Plan:
                 and out_map == (1, 0, 1, 0):
             # a plain 3x3 conv behind GroupNorm + Swish: the fp16-pair form of the split-operand kernel (its input range is known)
             pk.enable_h2(pk._x3_src, *act_range)
-        d.wp_h2, d.act_scale = _ptr(pk.wp2), _ptr(pk.act_scale)
+        if act_range is not None:      # only calls that carry the range take the fp16-pair form (a pack reused without one runs the triples)
+            d.wp_h2, d.act_scale = _ptr(pk.wp2), _ptr(pk.act_scale)
         for i in range(pk.ntaps):
             d.tap_dy[i], d.tap_dx[i] = pk.taps.dy[i], pk.taps.dx[i]
         need = C.c_int64(0)
@@ -305,10 +314,10 @@ class Plan:
             self.free(ws)
 
     def attention_workspace(self, B: int, Cc: int, heads: int, L: int) -> Optional[torch.Tensor]:
-        """Scratch for hdiff_mha_flash_fwd_ws (the operands as bf16 pieces, written and read inside that one call when the
-        contraction mode is bf16x3): sized by the library from the shape alone; allocated only when the plan is built in that mode."""
-        if self.lib.hdiff_get_contraction_mode() != 1:      # f32 mode: the kernels never touch it (plans are keyed by the mode; a plan
-            return None                                     # built here and run in the other mode splits inside the loop, as without a workspace)
+        """Scratch for hdiff_mha_flash_fwd_ws (the operands as fp16 pieces, written and read inside that one call when the
+        contraction mode is bf16x3): sized by the library from the SHAPE alone and allocated whatever the mode is now -- plans are
+        keyed by shape, not by mode, and a plan first built in the f32 mode must not run the slower in-loop-split kernel once the
+        mode is switched (tests/test_gpu_end_to_end.py builds its plan in f32 and asserts the pre-split kernel ran)."""
         need = C.c_int64(0)
         _capi.check(self.lib.hdiff_mha_flash_fwd_workspace(B, Cc, heads, L, C.byref(need)), "mha_flash_fwd_workspace")
         return self.buf((need.value + 3) // 4) if need.value > 0 else None

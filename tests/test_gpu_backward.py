@@ -250,6 +250,39 @@ def test_attention_backward_fp16_pairs_ranges(case, d):
             assert r2 <= 4.0 * r0, (case, name, b, h, r2, r0)
 
 
+def test_attention_backward_slab_cap_setting():
+    """HDIFF_BWD_SLAB_GIB (a deployment setting, read once per process: a fresh process here) caps the dQ partial slabs: with 1 GiB a
+    B = 32, L = 8192, d_head 16 backward is cut into 8 key ranges per (sample, head) instead of the 16 the default 16 GiB allows -- a smaller
+    workspace, another summation order of the dQ partials, the same gradients to fp32 rounding."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, hdiff_amd
+import _attn_bwd_cases as K
+lib = hdiff_amd.lib(); lib.hdiff_set_contraction_mode(1)
+g = torch.Generator().manual_seed(3)
+qkv, d_o = K.make_case("plain", 16, 8192, 32, 8, g)
+need = C.c_int64(0); assert lib.hdiff_mha_flash_bwd_workspace(32, 128, 8, 8192, C.byref(need)) == 0
+dqkv = K.run_bwd(lib, qkv.to(K.DEV), d_o.to(K.DEV), 8, 1)
+assert torch.isfinite(dqkv).all()
+torch.save(dqkv.cpu(), sys.argv[1]); print("WS_FLOATS", need.value)
+''' % (root, os.path.join(root, "tests"))
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, env in (("default", {k: v for k, v in os.environ.items() if k != "HDIFF_BWD_SLAB_GIB"}), ("1GiB", dict(os.environ, HDIFF_BWD_SLAB_GIB="1"))):
+            path = os.path.join(tmp, tag + ".pt")
+            res = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=env)
+            assert res.returncode == 0 and "WS_FLOATS" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+            outs[tag] = (torch.load(path), int(res.stdout.split("WS_FLOATS")[1].split()[0]))
+    (g16, ws16), (g1, ws1) = outs["default"], outs["1GiB"]
+    assert ws1 < ws16, (ws1, ws16)                                        # fewer key ranges -> fewer slabs
+    assert not torch.equal(g1, g16)                                       # another summation order ...
+    assert (g1 - g16).abs().max().item() <= 2e-6 * g16.abs().max().item()      # ... of the same sums
+
+
 def test_linear_and_embedding_backward():
     g = torch.Generator().manual_seed(2)
     table = torch.randn(12, 64, generator=g)

@@ -256,7 +256,8 @@ def test_split_bf16_conv_refuses_a_permuted_or_repeated_tap_list():
 def test_sampler_runs_with_autograd_enabled_like_the_reference():
     """The reference's sampler can be called with autograd on (DiffusionCondition.py:82-98; it then records a graph nobody
     differentiates).  Here the loop enters torch.no_grad() itself: same values as under no_grad, a detached result, one
-    RuntimeWarning per process."""
+    RuntimeWarning per sampler INSTANCE (a second sampler warns again: ADVICE round 4), and an x_T that requires grad -- a caller
+    who expects that graph -- is refused."""
     import warnings
     m = small(seed=4).cuda().eval()
     cfg = SMALL
@@ -267,12 +268,15 @@ def test_sampler_runs_with_autograd_enabled_like_the_reference():
     noise = torch.randn(cfg["T"], 2, 3, 16, 16, generator=g).cuda()
     with torch.no_grad():
         want = s(x, lab, noise_by_step=noise)
-    DC._WARNED_SAMPLER_GRAD = False
+    s2 = DC.GaussianDiffusionSampler(m, 1e-4, 0.02, cfg["T"], w=1.2).cuda()
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
         assert torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters())
         got = s(x, lab, noise_by_step=noise)
         again = s(x, lab, noise_by_step=noise)
-    assert torch.equal(got, want) and torch.equal(again, want)
+        other = s2(x, lab, noise_by_step=noise)
+    assert torch.equal(got, want) and torch.equal(again, want) and torch.equal(other, want)
     assert not got.requires_grad and got.grad_fn is None
-    assert sum(issubclass(r.category, RuntimeWarning) and "autograd enabled" in str(r.message) for r in rec) == 1
+    with pytest.raises(RuntimeError, match="requires grad"):
+        s(x.clone().requires_grad_(True), lab, noise_by_step=noise)
+    assert sum(issubclass(r.category, RuntimeWarning) and "autograd enabled" in str(r.message) for r in rec) == 2      # once per instance

@@ -63,6 +63,11 @@ def test_c1_sampling_64x64_T50_matches_cpu_path():
             print(f"C1 {mode}: worst pre-clip trajectory error {worst:.2e}, PSNR {psnr:.1f} dB, SSIM {ssim:.6f}")
             # measured: 1.9e-6 / 144 dB in both modes (SURVEY 8(d) asks for >= 40 dB)
             assert worst < 5e-5 and psnr >= 100.0 and ssim >= 0.999999, (mode, worst, psnr, ssim)
+        # the plan was BUILT in the f32 mode and then run in bf16x3: its attention calls must carry the workspace all the same
+        # (sized from the shape alone), or the bf16x3 leg above would have run the slower in-loop-split kernel
+        plan = m.plan_for(2 * x_T.shape[0], x_T.shape[2], x_T.shape[3], torch.device(DEV))
+        att = [args for name, _, args in plan.plan.ops if name == "hdiff_mha_flash_fwd_ws"]
+        assert att and all(a[7] is not None and a[8].value > 0 for a in att if a[6] >= 512), [(a[6], a[7]) for a in att]
     finally:
         hdiff_amd.set_contraction_mode(before)
 

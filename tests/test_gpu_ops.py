@@ -770,42 +770,6 @@ def test_randn_moments_and_determinism():
     assert torch.isfinite(a).all()
 
 
-def test_flash_attention_x3p_kernel_at_d_head_16_behind_its_dev_knob():
-    """attention_x3p.hip also runs d_head 16 (a 32-row tile then carries two V pieces); the default dispatch prefers the
-    16x16x32 kernel there, so the path is kept alive here through its knob (HDIFF_X3P=1, read once per process)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import ctypes as C, math, sys
-sys.path.insert(0, %r)
-import torch, hdiff_amd
-lib = hdiff_amd.lib(); hdiff_amd.set_contraction_mode("bf16x3")
-g = torch.Generator().manual_seed(5)
-heads, d, L, B = 8, 16, 2048, 2
-Cc = heads * d
-qkv = (torch.randn(B, 3 * Cc, L, generator=g) * 1.5).cuda()
-q, k, v = [z.reshape(B, heads, d, L).transpose(2, 3).double() for z in qkv.split(Cc, dim=1)]
-ref = (torch.softmax(q @ k.transpose(2, 3) / math.sqrt(d), dim=-1) @ v).transpose(2, 3).reshape(B, Cc, L)
-need = C.c_int64(0); lib.hdiff_mha_flash_fwd_workspace(B, Cc, heads, L, C.byref(need))
-ws = torch.empty(need.value // 4 + 1, device="cuda"); s = torch.cuda.current_stream().cuda_stream
-def run(with_ws):
-    o = torch.empty(B, Cc, L, device="cuda")
-    rc = lib.hdiff_mha_flash_fwd_ws(qkv.data_ptr(), o.data_ptr(), None, B, Cc, heads, L, ws.data_ptr() if with_ws else None,
-                                    need.value if with_ws else 0, s)
-    assert rc == 0, lib.hdiff_last_error(); torch.cuda.synchronize(); return o
-a, b = run(True), run(False)
-assert not torch.equal(a, b), "the 32x32x16 kernel did not run"          # a different program than the in-loop split
-err = (a.double() - ref).abs().max().item(); err_b = (b.double() - ref).abs().max().item()
-assert err <= 2.0 * err_b + 1e-9 and err < 5e-6, (err, err_b)
-print("X3P16_OK", err, err_b)
-''' % root
-    env = dict(os.environ, HDIFF_X3P="1", HDIFF_PV="bf16x3")      # the bf16-triple P.V kernels (round 3), and of those the 32x32x16 one
-    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
-    assert res.returncode == 0 and "X3P16_OK" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
-
-
 @pytest.mark.parametrize("Cc,H,W,B", [(64, 64, 64, 16), (128, 32, 96, 8)])      # >= 192 workgroups per phase launch
 def test_upsample_phases_on_the_split_bf16_kernel(Cc, H, W, B, bf16x3_mode):
     """UpSample.forward (ModelCondition.py:85-89): ConvTranspose2d(C, C, 5, 2, 2, 1) as four output-parity phases + Conv3x3.
