@@ -29,7 +29,8 @@ fi
 run_pmc() {   # name, counters..., then -- command   (environment of the caller is inherited: HDIFF_CONTRACT=f32 run_pmc ...)
   local name=$1; shift
   local ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
-  rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d $P/$name -o pmc -- "$@" > /dev/null 2>&1
+  timeout -k 10 ${PMC_TIMEOUT:-240} rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d $P/$name -o pmc -- "$@" > $P/$name.out 2> $P/$name.err \
+    || echo "pmc pass $name failed or timed out (rc $?): see $P/$name.err" | tee -a $P/failed.txt
 }
 if want pmc1; then
 run_pmc x3_sq1 $SQ1 -- python3 tools/attn_once.py 16
@@ -40,6 +41,8 @@ run_pmc bwd_sq2 $SQ2 -- python3 tools/attn_bwd_once.py 4
 HDIFF_CONTRACT=f32 run_pmc bwdf32_sq1 $SQ1 -- python3 tools/attn_bwd_once.py 4
 run_pmc bwd32_sq1 $SQ1 -- python3 tools/attn_bwd_once.py 4 256 16384
 run_pmc bwd32_sq2 $SQ2 -- python3 tools/attn_bwd_once.py 4 256 16384
+run_pmc fwd32_sq1 $SQ1 -- python3 tools/attn_once.py 16 256 16384
+run_pmc fwd32_sq2 $SQ2 -- python3 tools/attn_once.py 16 256 16384
 run_pmc convx3_sq1 $SQ1 -- python3 tools/conv_once.py 16 128 128 256 3 gn
 run_pmc convh2_sq1 $SQ1 -- python3 tools/conv_once.py 16 128 128 256 3 pairs
 run_pmc convh2_sq2 $SQ2 -- python3 tools/conv_once.py 16 128 128 256 3 pairs
@@ -62,11 +65,12 @@ if want summary; then
   echo "## attn_sq1: HDIFF_CONTRACT=f32 ... -- python3 tools/attn_once.py 16"; python3 tools/pmc_summary.py $P/attn_sq1/pmc_counter_collection.csv "fast_kernel<16"
   for d in bwd_sq1 bwd_sq2; do echo "## $d: ... -- python3 tools/attn_bwd_once.py 4   (bf16x3 mode: maxima + split pass + mha_bwd_h2_kernel<16> + slab reduce)"; python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv mha_bwd_h2_kernel; done
   for d in bwd32_sq1 bwd32_sq2; do echo "## $d: ... -- python3 tools/attn_bwd_once.py 4 256 16384   (d_head 32, L = 16384: mha_bwd_h2_kernel<32>)"; python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv mha_bwd_h2_kernel; done
+  for d in fwd32_sq1 fwd32_sq2; do echo "## $d: ... -- python3 tools/attn_once.py 16 256 16384   (d_head 32 forward, L = 16384: mha_flash_fwd_x3p_kernel, fp16 pairs)"; python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv mha_flash_fwd_x3p; done
   echo "## bwdf32_sq1: HDIFF_CONTRACT=f32 ... -- python3 tools/attn_bwd_once.py 4"; python3 tools/pmc_summary.py $P/bwdf32_sq1/pmc_counter_collection.csv mha_bwd_fused
   echo "## convx3_sq1: ... -- python3 tools/conv_once.py 16 128 128 256 3 gn   (bf16 triples: round 3's kernel, still the one for 3x3 convs without a GroupNorm prologue)"; python3 tools/pmc_summary.py $P/convx3_sq1/pmc_counter_collection.csv conv3x3_x3
   for d in convh2_sq1 convh2_sq2; do echo "## $d: ... -- python3 tools/conv_once.py 16 128 128 256 3 pairs   (fp16 pairs: conv3x3_x3_kernel<9, false, true>)"; python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv conv3x3_x3; done
   echo "## conv_sq1: HDIFF_CONTRACT=f32 ... -- python3 tools/conv_once.py 16 128 128 256 3 gn"; python3 tools/pmc_summary.py $P/conv_sq1/pmc_counter_collection.csv conv_igemm
-  for k in x3 attn conv convh2 gn bwd bwdf32; do for c in FETCH_SIZE WRITE_SIZE; do echo "## ${k}_$c (KiB per dispatch)"; python3 tools/pmc_summary.py $P/${k}_$c/pmc_counter_collection.csv | grep -A1 -E "mha_flash_fwd_h2_kernel|qkv_split3|v_split_h2|fast_kernel<16|igemm_kernel<2, 8, 12, 5, 1|conv3x3_x3|gn_stats_kernel|bwd_fused|bwd_h2|bwd_split|absmax|dq_reduce|delta"; done; done
+  for k in x3 attn conv convh2 gn bwd bwdf32; do for c in FETCH_SIZE WRITE_SIZE; do echo "## ${k}_$c (KiB per dispatch)"; python3 tools/pmc_summary.py $P/${k}_$c/pmc_counter_collection.csv | grep -A1 -E "mha_flash_fwd_h2_kernel|qk_split_h2|qk_rowmax|v_split_h2|fast_kernel<16|igemm_kernel<2, 8, 12, 5, 1|conv3x3_x3|gn_stats_kernel|bwd_fused|bwd_h2|bwd_split|absmax|dq_reduce|delta"; done; done
 } > $P/pmc_summary.txt
 python3 tools/traffic_json.py $P $COMMIT --out $P/roofline_traffic.json > $P/traffic_line.json 2> $P/traffic.err
 fi

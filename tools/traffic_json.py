@@ -26,7 +26,7 @@ ENTRIES = (
     ("mha_flash_bwd_L65536_B4", "bwd_fused", "bwdf32", True, ["attention_bwd.hip", "common.h"]),
 )
 ALGORITHMIC = {
-    "mha_flash_fwd_L65536_B16_bf16x3": 16 * 128 * 65536 * (6 + 6 + 4 + 4),   # main kernel (round 4): q, k as bf16 triples (6 B per element), v as an fp16 pair (4 B) read, o written
+    "mha_flash_fwd_L65536_B16_bf16x3": 16 * 128 * 65536 * (4 + 8 + 4 + 4),   # main kernel (round 5): q as two fp16 pieces (4 B per element), k as four (8 B), v as an fp16 pair (4 B) read, o written
     "conv3x3_128_256_B16_pairs": 1074331648,
     "mha_flash_fwd_L65536_B16": 2147483648, "conv3x3_128_256_B16": 1074331648, "gn_stats_128_256_B16": 536870912,
     "mha_flash_bwd_L65536_B4": 4 * 65536 * 128 * 4 * 8,      # q, k, v, o, dO read; dq, dk, dv written: 8 tensors of B*C*L floats
