@@ -1,20 +1,35 @@
 // Backward of the flash self-attention core at d_head 16 and 32 in the split-operand mode.  Round 3 built it on bf16 triples
 // throughout (attention_bwd_x3.hip, retired in round 5: git show 6a5a4b1 has it); round 4 moved everything that touches
-// P = exp2(S - lse) or the pair (dO, V) to fp16 PAIRS
-// (attention_h2.hip has the argument and the instructions: v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16, 1.5 per value against 5.5).
+// P = exp2(S - lse) or the pair (dO, V) to fp16 PAIRS; round 5 moves the rest: EVERY operand is an fp16 pair now.
 // Same contract, layouts and dQ slab protocol (reference: autograd through nn.MultiheadAttention, ModelCondition.py:189,
 // 204-208, TrainCondition.py:60): bitwise reproducible.
 //
-//   S   = Q K^T - lse2 + 14      bf16 triples, six products (an error in S is an error in an exponent: stays as it was)
-//   dP' = dO' V'^T - delta'      dO' = dO 2^so, V' = V 2^sv as fp16 pairs, FOUR products (a pair holds 22-23 bits, the
-//                                fp32-class sum of products needs both cross terms; tools/h2_sim_qk.py); so, sv: powers of
-//                                two per (sample, head) that put the tensor's maximum in [2^14, 2^15) (mha_bwd_absmax_kernel);
-//                                delta' = delta 2^(so + sv) is scaled when the tile is staged
-//   P'  = exp2(S)                = P 2^14 <= 2^14: always inside fp16, no reference to move; two fp16 pieces
-//   dS' = P' o dP'               = dS 2^(14 + so + sv), fp32; its magnitude is unbounded both ways -- bf16 triples as before
-//   dV'^T += dO'^T P'            three products (o0 p0, o1 p0, o0 p1) instead of six
-//   dK'^T += Q^T dS' ,  dQ'^T += K^T dS'^T    unchanged; the powers of two leave with the final scaling of each output
-// Per 16x16 (query, key) tile at d 16: 12.5 MFMAs and ~36 vector instructions per lane against 15 and ~52.
+// A pair is x = x0 + x1 with x0 = fp16(x) and x1 = fp16 of the exact residual: 2^-22 |x| at worst as long as x1 is a NORMAL fp16
+// number.  Two ways to keep it one:
+//   (i)  "balance per product term" (attention_h2.hip): store x1 2^8 and give its partner in the product 2^-8 -- stored (K, V:
+//        stationary operands) or made by one v_pk_mul_f16 per operand word.  For operands whose magnitude is whatever the model
+//        produces (Q, K with the forward's balance a; P', dS').
+//   (ii) scale the whole tensor by a power of two that puts its maximum in [2^13, 2^14): then the UNshifted x1 resolves 2^-24
+//        absolute = 2^-38 of the maximum.  For operands this file makes its own copy of anyway (below).
+//   S    = Q K^T - lse2 + 14     q = Q qscale 2^-a, k = K 2^a (a per (sample, head)); four terms
+//                                q0 k0 + (q1 2^8)(k0 2^-8) | (q0 2^-8)(k1 2^8) + q1 k1: two MFMAs per tile at d 16 (bf16 triples: three);
+//                                d 32: three MFMAs, the 2^-24 term q1 k1 dropped
+//   dP'  = dO' V'^T - delta'     V' = V 2^sv per (sample, head); dO'_q = dO_q 2^(so + t_q) per QUERY position: every row's maximum in
+//                                [2^13, 2^14) (t_q = exponent of the head's loudest position minus that of position q, 0 .. 24).  One loud
+//                                position no longer decides the scale of everybody's dS' row (tests: "one pixel of dO 1e4 x the rest").
+//                                The same four-term form; |dP' - delta'| <= 2^(29 + log2 d)
+//   P'   = exp2(S) = P 2^14      two pieces (p0, p1): v_cvt_pk_f16_f32 + v_fma_mixlo / mixhi_f16
+//   dS'  = (P' o dP') 2^-(28 + log2 d)   <= 2^15: inside fp16 by construction; two pieces (s0, s1 2^8), the factor applied inside the split's own
+//                                conversions (split2_scaled; the SHIFTED residual is what keeps a flat softmax over 65 536 keys precise)
+//   dV'^T += (dO 2^so)^T P'      o0 p0 + o0 p1 + o1 p0: dO with the HEAD's scale alone (a second staged copy, form (ii): unshifted pieces) --
+//                                P' needs no per-query factor and the three products share one accumulator
+//   dK'^T += (Q 2^sq c_q)^T dS'  q0 s0 + (q0 2^-8)(s1 2^8) + q1 s0: a copy of the Q rows that gives the per-query factor c_q = 2^-t_q
+//                                back, form (ii); q0 2^-8 by v_pk_mul_f16 after the transposed read
+//   dQ'^T += k^T dS'^T           a: k0 s0, b: (k1 2^8) s0 + k0 (s1 2^8); a + b 2^-8 and the factor c_q when the tile leaves
+// Per 16x16 (query, key) tile at d 16: 8.5 MFMAs and ~30 vector instructions per lane (round 4: 12.5 / ~36; round 3: 15 / ~52).
+// Error class (tests/test_gpu_backward.py, profiles/r05_attention_bwd_error_ratio.txt): rms against float64 <= the fp32-input
+// kernel's on every input family tried; the worst ELEMENT up to 2.3x (3x for one (sample, head) pair) -- where one score dominates
+// a row the pair's 2^-22 operand rounding is the whole error.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -32,7 +47,7 @@ constexpr int THREADS = 256;
 constexpr int KB = 128;                // keys per workgroup block (32 per wave)
 constexpr int SROW = 72;               // bytes per key row of the dS image [key][32 queries] (64 + 8: conflict-free ds_write_b64)
 constexpr int SPART = 32 * SROW;       // 2304 per piece
-constexpr int SCRB = 3 * SPART;        // 6912 per wave
+constexpr int SCRB = 2 * SPART;        // 4608 per wave (two pieces of dS)
 
 // Geometry by head width.  d 16: tiles of 64 queries (two subtiles of 32 = one contraction of the q-summed products), rows of
 // 32 bytes -- with ds_read_b128's real lane groups ({0-3, 12-15, 20-27}, ...) plain 32-byte rows are conflict-free for the row
@@ -49,15 +64,15 @@ struct Geo {
                                                       // row and transposed reads alike, measured no faster: 16.39 vs 16.35 ms)
   static constexpr int CPR = GROW / 16;               // 16-byte chunks per row
   static constexpr int RPART = TQ * RROW;
-  static constexpr int QA_OFF = 0, OA_OFF = 3 * RPART;           // three bf16 pieces of Q rows, two fp16 pieces of dO rows
-  static constexpr int SL_OFF = 5 * RPART, SD_OFF = SL_OFF + TQ * 4, BUFB = SD_OFF + TQ * 4;
+  // rows of (q0, q1 2^8); of q c_q likewise; of dO scaled per query (o0, o1 2^8); of dO scaled per head likewise
+  static constexpr int QA_OFF = 0, QE_OFF = 2 * RPART, OA_OFF = 4 * RPART, OH_OFF = 6 * RPART;
+  static constexpr int SL_OFF = 8 * RPART, SD_OFF = SL_OFF + TQ * 4, SC_OFF = SD_OFF + TQ * 4, BUFB = SC_OFF + TQ * 4;
   static constexpr int DQS = TQ + 4;                  // row stride (floats) of a wave's dQ partial tile [D][DQS], aliased on its scratch
   static_assert(TQ * GROW == 2048, "staging geometry: 128 chunks per piece");
   static_assert(D * DQS * 4 <= SCRB, "dQ partial tile must fit in the wave's scratch");
   static_assert(2 * BUFB + 4 * SCRB <= 65536, "static LDS");
 };
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -71,31 +86,12 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
   return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
 }
 
-__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {
-  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
-}
-__device__ __forceinline__ float top16(float x) {
-  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u);
-}
-// (a, b) -> three packed bf16 pairs, a = a0 + a1 + a2 exactly (truncation split; plain VALU only, see attention_x3.hip)
-__device__ __forceinline__ void split3(float a, float b, unsigned& h0, unsigned& h1, unsigned& h2) {
-  h0 = pack_hi16(a, b);
-  const float ra = a - top16(a), rb = b - top16(b);
-  h1 = pack_hi16(ra, rb);
-  const float sa = ra - top16(ra), sb = rb - top16(rb);
-  h2 = pack_hi16(sa, sb);
-}
-
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores
 // (release fence: s_waitcnt vmcnt(0)); with one slab store per tile in flight that wait exposed the store's latency at
 // every barrier -- 23 ms of a 158 ms launch (timing ablation).  Nothing here hands global data to another wave.
 __device__ __forceinline__ void lds_barrier() {
   if (H2B_ABL & 256) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
@@ -112,31 +108,78 @@ __device__ __forceinline__ void split2(float a, float b, float one, unsigned& h0
   h0 = u;
   h1 = __builtin_bit_cast(unsigned, r);
 }
-// power-of-two scale that puts a tensor's maximum |x| (given as the bits of the fp32 value) into [2^14, 2^15)
-__device__ __forceinline__ int scale_exp(unsigned amax_bits) {
-  int e = (int)((amax_bits >> 23) & 0xffu) - 127;
-  e = e < -50 ? -50 : (e > 50 ? 50 : e);       // all-zero / denormal / huge tensors: a fixed scale (inf and NaN stay what they are)
-  return 14 - e;
+// (a c, b c) -> two packed fp16 pairs with the SECOND piece times 2^8: h0 = fp16(a c) by v_fma_mixlo / mixhi_f16 (fma(a, c, 0)), r = the
+// EXACT residual fma(a, c, -h0) in fp32 (v_fma_mix_f32 reads h0 as fp16), h1 = fp16(256 r).  Three instructions per value (an unshifted
+// residual would take two: but dS' is typically 2^-7 where the softmax is flat over 65 536 keys -- the bound 2^15 belongs to a row that
+// is one-hot AND has |dP - delta| at its ceiling -- and an unshifted residual of that is a subnormal: dQ rms 1.45 x the fp32 kernel's at
+// L = 65 536 with N(0, 1) inputs).  In asm: from C the compiler makes the first piece a v_mul_f32 + a conversion.  Two value pairs per
+// statement so that no v_fma_mixhi follows its v_fma_mixlo directly.  `up` = 256.0f in a register.
+__device__ __forceinline__ void split2_scaled(float a0, float a1, float b0, float b1, float c, float up, unsigned& ha0, unsigned& ha1,
+                                              unsigned& hb0, unsigned& hb1) {
+  float r0, r1, r2, r3;
+  asm("v_fma_mixlo_f16 %0, %8, %12, 0\n\t"
+      "v_fma_mixlo_f16 %2, %10, %12, 0\n\t"
+      "v_fma_mixhi_f16 %0, %9, %12, 0\n\t"
+      "v_fma_mixhi_f16 %2, %11, %12, 0\n\t"
+      "s_nop 0\n\t"
+      "v_fma_mix_f32 %4, %8, %12, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %6, %10, %12, -%2 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %5, %9, %12, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %7, %11, %12, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %1, %4, %13, 0\n\t"
+      "v_fma_mixlo_f16 %3, %6, %13, 0\n\t"
+      "v_fma_mixhi_f16 %1, %5, %13, 0\n\t"
+      "v_fma_mixhi_f16 %3, %7, %13, 0\n\t"
+      "s_nop 0"
+      : "=&v"(ha0), "=&v"(ha1), "=&v"(hb0), "=&v"(hb1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(c), "v"(up));
+}
+constexpr int PAIR_SHIFT = 8;                 // second pieces are stored times 2^8
+constexpr unsigned PAIR_DOWN2 = 0x1c001c00u;  // (2^-8, 2^-8) as packed fp16
+// exponent e of a tensor's maximum |x| (given as the bits of the fp32 value), clamped: all-zero / denormal / huge tensors get a fixed
+// scale (inf and NaN stay what they are)
+__device__ __forceinline__ int max_exp(unsigned amax_bits) {
+  const int e = (int)((amax_bits >> 23) & 0xffu) - 127;
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+// V' = V 2^sv with the (sample, head)'s maximum in [2^13, 2^14).  dO is scaled PER QUERY: dO'_q = dO_q 2^(so + t_q), so the head's power
+// of two (maximum of the loudest position in [2^13, 2^14)) and t_q = (exponent of the head's maximum) - (exponent of position q's
+// maximum), clamped to 0 .. 24 -- every position's row sits at the top of fp16, and so does its row of dS'.  Where the contraction
+// runs over queries the factor c_q = 2^-t_q is given back by the OTHER operand: dV^T takes a copy of dO with the head's scale alone,
+// dK^T a copy of the Q rows times c_q (both staged beside the tiles of the score products); dQ_q is multiplied by c_q when it leaves.
+__device__ __forceinline__ int scale_exp_o(unsigned amax_bits) { return 13 - max_exp(amax_bits); }
+__device__ __forceinline__ int scale_exp_v(unsigned amax_bits) { return 13 - max_exp(amax_bits); }
+__device__ __forceinline__ int scale_exp_q(unsigned amax_bits) { return 13 - max_exp(amax_bits); }      // of the Q rows that enter dK^T
+constexpr int P_UP = 14;       // P' = exp2(S - lse2 + 14) <= 2^14, as in round 4 (the chain's initial value 14 - lse2 stays SMALL: with -17 - lse2
+                               // instead -- tried -- every accumulation of S rounds at the magnitude of ~33 and the exponent loses three bits)
+// dS' = P' (dP' - delta') 2^-DS_DOWN <= 2^15: |dP'| <= d 2^14 2^14, |delta'| = |sum_k P dP'| likewise, P' <= 2^14
+template <int D> constexpr int DS_DOWN = (D == 16) ? 32 : 33;
+// the score balance of this (sample, head): k = K 2^a, q = Q qscale 2^-a with the two maxima in the same binade (attention_h2.hip)
+__device__ __forceinline__ int balance_exp(unsigned qmax_bits, unsigned kmax_bits, float qscale) {
+  const float mq = __builtin_bit_cast(float, qmax_bits) * qscale;
+  const int eq = (int)((__builtin_bit_cast(unsigned, mq) >> 23) & 0xffu), ek = (int)((kmax_bits >> 23) & 0xffu);
+  int a = (eq == 0 || ek == 0 || eq == 255 || ek == 255) ? 0 : (eq - ek) / 2;
+  return a < -60 ? -60 : (a > 60 ? 60 : a);
 }
 
-// split-product terms kept (piece of the A-side tensor, piece of the B-side tensor): all i + j <= 2, small terms last
-__device__ constexpr int TERM_A[6] = {0, 1, 0, 2, 1, 0};
-__device__ constexpr int TERM_B[6] = {0, 0, 1, 0, 1, 2};
-
-// piece tensors of one (sample, head), each 3 pieces of L * D bf16
-enum { T_QA = 0, T_KB = 1, T_KT = 2, T_VB = 3, T_OA = 4, T_COUNT = 5 };
+// Piece slots of one (sample, head), each L * D fp16: rows of q (q0, q1 2^8); rows of Q 2^sq c_q (x0, x1); rows of k (k0, k0 2^-8,
+// k1 2^8, k1); k transposed [D][L] (k0, k1 2^8); rows of V' (v0, v0 2^-8, v1 2^8, v1); rows of dO scaled per query (o0, o1 2^8); rows of
+// dO scaled per head (x0, x1); the L factors c_q (fp32) in the last slot
+enum { S_Q = 0, S_QE = 2, S_K = 4, S_KT = 8, S_V = 10, S_O = 14, S_OH = 16, S_C = 18, S_COUNT = 19 };
+enum { M_V = 0, M_O = 1, M_Q = 2, M_K = 3, M_COUNT = 4 };      // maxima per (sample, head)
 
 // ---------------------------------------------------------------------------------------------------------------------
-// max |V| and max |dO| per (sample, head) as fp32 bit patterns (non-negative floats order like unsigned integers):
-// absmax[(b * heads + head) * 2 + {0: V, 1: dO}], zeroed by the launcher.  grid (L / 4096, 2 * heads, B).
+// max |V|, |dO|, |Q|, |K| per (sample, head) as fp32 bit patterns (non-negative floats order like unsigned integers):
+// absmax[(b * heads + head) * 4 + {V, dO, Q, K}], zeroed by the launcher.  grid (L / 4096, 4 * heads, B).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(THREADS) void mha_bwd_absmax_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                                  unsigned* __restrict__ absmax, int C, int L) {
   const int heads = C / D;
   const int which = blockIdx.y / heads, head = blockIdx.y - which * heads, b = blockIdx.z;
-  const float* src = (which == 0) ? qkv + ((size_t)b * 3 * C + 2 * (size_t)C + (size_t)head * D) * L
-                                  : d_o + ((size_t)b * C + (size_t)head * D) * L;
+  const int third = which == M_V ? 2 : (which == M_Q ? 0 : 1);
+  const float* src = (which == M_O) ? d_o + ((size_t)b * C + (size_t)head * D) * L
+                                    : qkv + ((size_t)b * 3 * C + (size_t)third * C + (size_t)head * D) * L;
   const int l0 = blockIdx.x * 4096;
   float m = 0.f;
   for (int d = 0; d < D; ++d)
@@ -146,73 +189,99 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_absmax_kernel(const float* __
     }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(absmax + ((size_t)b * heads + head) * 2 + which, __builtin_bit_cast(unsigned, m));
+  if ((threadIdx.x & 63) == 0) atomicMax(absmax + ((size_t)b * heads + head) * M_COUNT + which, __builtin_bit_cast(unsigned, m));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// fp32 qkv [B][3C][L] and dO [B][C][L] -> the five piece tensors.  grid (L / 256, 4 * heads, B): blockIdx.y / heads
-// selects Q, K, V or dO.  Q (pre-scaled), K: bf16 triples as rows [L][D], K also transposed [D][L].  V, dO: fp16 pairs of
-// the tensor times its power of two (scale_exp of the maxima above), rows [L][D], in piece slots 0 and 1.
+// fp32 qkv [B][3C][L] and dO [B][C][L] -> the piece tensors above.  grid (L / 256, 4 * heads, B): blockIdx.y / heads selects
+// Q, K, V or dO; thread = one position, all D channels (K^T: thread = two neighbouring positions of each channel).
+// The fp32 scaled value and the packed first pieces are made opaque to the compiler: left alone it rounds x0 twice (once from
+// the fp32 product for the stored piece, once from the exact product for the residual: attention_h2.hip).
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair4(float xa, float xb, float up, unsigned& x0, unsigned& x0s, unsigned& x1s, unsigned& x1) {
+  asm("" : "+v"(xa), "+v"(xb));
+  unsigned u0 = __builtin_bit_cast(unsigned, f16x2{(_Float16)xa, (_Float16)xb});
+  asm("" : "+v"(u0));
+  const f16x2 h = __builtin_bit_cast(f16x2, u0);
+  const float ra = xa - (float)h[0], rb = xb - (float)h[1];            // exact
+  const f16x2 dn = {(_Float16)(1.0f / (1 << PAIR_SHIFT)), (_Float16)(1.0f / (1 << PAIR_SHIFT))};
+  x0 = u0;
+  x0s = __builtin_bit_cast(unsigned, h * dn);
+  x1s = __builtin_bit_cast(unsigned, f16x2{(_Float16)(ra * up), (_Float16)(rb * up)});
+  x1 = __builtin_bit_cast(unsigned, f16x2{(_Float16)ra, (_Float16)rb});
+}
+
 template <int D>
 __global__ __launch_bounds__(THREADS) void mha_bwd_split_h2_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                                    __bf16* __restrict__ ws, const unsigned* __restrict__ absmax,
                                                                    int C, int L, float qscale, float one) {
   const int heads = C / D;
-  const int which = blockIdx.y / heads, head = blockIdx.y - which * heads, b = blockIdx.z;
+  const int which = blockIdx.y / heads, head = blockIdx.y - which * heads, b = blockIdx.z;     // 0: Q, 1: K, 2: V, 3: dO
   const float* src = (which < 3) ? qkv + ((size_t)b * 3 * C + (size_t)which * C + (size_t)head * D) * L
                                  : d_o + ((size_t)b * C + (size_t)head * D) * L;
   const size_t piece = (size_t)L * D;
-  __bf16* base = ws + ((size_t)b * heads + head) * (T_COUNT * 3) * piece;
-  const int t_rows = which == 0 ? T_QA : which == 1 ? T_KB : which == 2 ? T_VB : T_OA;
-  const int t_tr = which == 1 ? T_KT : -1;
+  __bf16* base = ws + ((size_t)b * heads + head) * S_COUNT * piece;
+  const unsigned* mx = absmax + ((size_t)b * heads + head) * M_COUNT;
+  const int a = balance_exp(mx[M_Q], mx[M_K], qscale);
+  const float sc = which == 0 ? qscale * __builtin_ldexpf(1.0f, -a) : which == 1 ? __builtin_ldexpf(1.0f, a)
+                 : which == 2 ? __builtin_ldexpf(1.0f, scale_exp_v(mx[M_V])) : __builtin_ldexpf(1.0f, scale_exp_o(mx[M_O]));
+  const float up = (float)(1 << PAIR_SHIFT) * one;
   const int l = blockIdx.x * THREADS + threadIdx.x;
-  if (which >= 2) {
-    if (l >= L) return;
-    const float sc = __builtin_ldexpf(1.0f, scale_exp(absmax[((size_t)b * heads + head) * 2 + (which - 2)]));
-    unsigned h[2][D / 2];
+  if (l < L) {
+    // t_q of this position (the Q and the dO blocks): exponent of the head's dO maximum minus that of the position's own
+    int tq = 0;
+    if (which == 0 || which == 3) {
+      const float* dsrc = d_o + ((size_t)b * C + (size_t)head * D) * L + l;
+      float rm = 0.f;
 #pragma unroll
-    for (int j = 0; j < D / 2; ++j) split2(src[(size_t)(2 * j) * L + l] * sc, src[(size_t)(2 * j + 1) * L + l] * sc, one, h[0][j], h[1][j]);
-    __bf16* dst = base + (size_t)t_rows * 3 * piece;
+      for (int d = 0; d < D; ++d) rm = fmaxf(rm, fabsf(dsrc[(size_t)d * L]));
+      tq = max_exp(mx[M_O]) - ((int)((__builtin_bit_cast(unsigned, rm) >> 23) & 0xffu) - 127);
+      tq = tq < 0 ? 0 : (tq > 24 ? 24 : tq);
+      if (which == 3) reinterpret_cast<float*>(base + (size_t)S_C * piece)[l] = __builtin_ldexpf(1.0f, -tq);      // c_q
+    }
+    const float scq = which == 3 ? sc * __builtin_ldexpf(1.0f, tq) : sc;
+    unsigned h[4][D / 2];          // x0, x0 2^-8, x1 2^8, x1 as packed fp16 pairs (channels 2 j, 2 j + 1)
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      u32x4* o = reinterpret_cast<u32x4*>(dst + p * piece + (size_t)l * D);
+    for (int j = 0; j < D / 2; ++j)
+      pair4(src[(size_t)(2 * j) * L + l] * scq, src[(size_t)(2 * j + 1) * L + l] * scq, up, h[0][j], h[1][j], h[2][j], h[3][j]);
+    // Q, dO: (x0, x1 2^8); K, V: all four
+    const int slot0 = which == 0 ? S_Q : which == 1 ? S_K : which == 2 ? S_V : S_O;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const bool two = (which == 0 || which == 3);
+      if (two && (p == 1 || p == 3)) continue;
+      const int slot = slot0 + (two ? (p == 0 ? 0 : 1) : p);
+      u32x4* o = reinterpret_cast<u32x4*>(base + (size_t)slot * piece + (size_t)l * D);
 #pragma unroll
       for (int j = 0; j < D / 8; ++j) o[j] = u32x4{h[p][4 * j], h[p][4 * j + 1], h[p][4 * j + 2], h[p][4 * j + 3]};
     }
-    return;
-  }
-  const float sc = which == 0 ? qscale : 1.0f;
-  {
-    if (l < L) {
-      unsigned h[3][D / 2];
+    if (which == 0 || which == 3) {
+      // the A operands of the products that sum over queries: rows of Q 2^sq c_q (dK^T) / of dO 2^so (dV^T), the head's maximum in
+      // [2^13, 2^14) -- with that scale the SECOND piece needs no shift (x1 unshifted resolves 2^-24 absolute = 2^-38 of the maximum): (x0, x1)
+      const float s2 = which == 0 ? __builtin_ldexpf(1.0f, scale_exp_q(mx[M_Q]) - tq) : sc;
 #pragma unroll
-      for (int j = 0; j < D / 2; ++j) {
-        const float a = src[(size_t)(2 * j) * L + l] * sc, c = src[(size_t)(2 * j + 1) * L + l] * sc;
-        split3(a, c, h[0][j], h[1][j], h[2][j]);
-      }
-      __bf16* dst = base + (size_t)t_rows * 3 * piece;
+      for (int j = 0; j < D / 2; ++j)
+        pair4(src[(size_t)(2 * j) * L + l] * s2, src[(size_t)(2 * j + 1) * L + l] * s2, up, h[0][j], h[1][j], h[2][j], h[3][j]);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        u32x4* o = reinterpret_cast<u32x4*>(dst + p * piece + (size_t)l * D);
+      for (int p = 0; p < 2; ++p) {
+        u32x4* o = reinterpret_cast<u32x4*>(base + (size_t)((which == 0 ? S_QE : S_OH) + p) * piece + (size_t)l * D);
 #pragma unroll
-        for (int j = 0; j < D / 8; ++j) o[j] = u32x4{h[p][4 * j], h[p][4 * j + 1], h[p][4 * j + 2], h[p][4 * j + 3]};
+        for (int j = 0; j < D / 8; ++j) o[j] = u32x4{h[3 * p][4 * j], h[3 * p][4 * j + 1], h[3 * p][4 * j + 2], h[3 * p][4 * j + 3]};
       }
     }
   }
-  if (t_tr >= 0) {
-    __bf16* dst = base + (size_t)t_tr * 3 * piece;
+  if (which == 1) {          // K transposed [D][L]: (k0, k1 2^8)
+    __bf16* dst = base + (size_t)S_KT * piece;
     const int l2 = (int)blockIdx.x * (THREADS / 2) + (int)threadIdx.x;       // the block's 256 positions = 128 pairs: half the threads
     if ((int)threadIdx.x < THREADS / 2 && 2 * l2 < L) {
 #pragma unroll 4
       for (int d = 0; d < D; ++d) {
         const f32x2 v = *reinterpret_cast<const f32x2*>(src + (size_t)d * L + 2 * l2);
-        unsigned h0, h1, h2;
-        split3(v[0] * sc, v[1] * sc, h0, h1, h2);
+        unsigned x0, x0s, x1s, x1;
+        pair4(v[0] * sc, v[1] * sc, up, x0, x0s, x1s, x1);
         unsigned* o = reinterpret_cast<unsigned*>(dst + (size_t)d * L) + l2;
-        o[0] = h0;
-        o[piece / 2] = h1;
-        o[piece] = h2;
+        o[0] = x0;
+        o[piece / 2] = x1s;
       }
     }
   }
@@ -226,8 +295,8 @@ struct BwdH2Args {
   float* dq_part;             // partial dQ slabs, as in attention_bwd.hip
   size_t split_stride, batch_stride;
   int C, L, kb_per_split;
-  float inv_sqrt_d;
-  const unsigned* absmax;     // max |V|, max |dO| per (sample, head): mha_bwd_absmax_kernel
+  float inv_sqrt_d, qscale;
+  const unsigned* absmax;     // max |V|, |dO|, |Q|, |K| per (sample, head): mha_bwd_absmax_kernel
   float one;                  // 1.0f, opaque to the compiler (split2)
 };
 
@@ -235,12 +304,14 @@ template <int D>
 __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args a) {
   using G = Geo<D>;
   constexpr int TQ = G::TQ, NSUB = G::NSUB, MT = G::MT, RROW = G::RROW, GROW = G::GROW, CPR = G::CPR, RPART = G::RPART, BUFB = G::BUFB, DQS = G::DQS;
-  constexpr int QA_OFF = G::QA_OFF, OA_OFF = G::OA_OFF, SL_OFF = G::SL_OFF, SD_OFF = G::SD_OFF;
-  constexpr int TPM = 32 / D;                  // terms per d-contracted MFMA: d 16 packs two piece products along the 32 slots
-  constexpr int NQK = 6 / TPM;                 // MFMAs of one 16x16 score tile
-  constexpr int NOP = 3;                       // Q / K: operand registers per 16 rows of a d-contracted operand (sets at d 16, pieces at d 32)
-  constexpr int NOA = (D == 16) ? 1 : 2;       // dO: [o0 | o1] along the 32 slots at d 16, the two pieces at d 32
-  constexpr int NVB = 2;                       // V: [v0 | v0], [v1 | v1] at d 16, the two pieces at d 32
+  constexpr int QA_OFF = G::QA_OFF, QE_OFF = G::QE_OFF, OA_OFF = G::OA_OFF, OH_OFF = G::OH_OFF, SL_OFF = G::SL_OFF, SD_OFF = G::SD_OFF, SC_OFF = G::SC_OFF;
+  // d-contracted products (S, dP'), four terms x0 y0, (x1 2^8)(y0 2^-8), (x0 2^-8)(y1 2^8), x1 y1:
+  //   d 16: two terms share an MFMA's 32 slots -- row operand A0 = (x0 | x1 2^8) as staged, A1 = A0 2^-8; stationary B0 = (y0 | y0 2^-8),
+  //         B1 = (y1 2^8 | y1): 2 MFMAs;   d 32: one term per MFMA and the 2^-22 term x1 y1 dropped (the d_head 32 forward does the same:
+  //         its error against float64 does not move) -- A = x0, x1 2^8, x0 2^-8; B = y0, y0 2^-8, y1 2^8: 3 MFMAs
+  constexpr int NA = (D == 16) ? 1 : 2;        // row operands READ per 16 rows
+  constexpr int NT = (D == 16) ? 2 : 3;        // MFMAs of one d-contracted 16x16 tile = stationary operand sets per 16 keys; operands NA .. NT - 1 are
+                                               // the first NT - NA read ones times 2^-8
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB + 4 * SCRB];
 
   const int C = a.C, L = a.L;
@@ -249,9 +320,10 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
   const TileId tile = xcd_tile();
   const int head = tile.head, b = tile.b, heads = gridDim.y, split = tile.x;
   const size_t piece_n = (size_t)L * D;
-  const __bf16* wsh = a.ws + ((size_t)b * heads + head) * (T_COUNT * 3) * piece_n;
+  const __bf16* wsh = a.ws + ((size_t)b * heads + head) * S_COUNT * piece_n;
   const float* lbase = a.lse2 + ((size_t)b * heads + head) * L;
   const float* dbase = a.delta + ((size_t)b * heads + head) * L;
+  const float* cbase = reinterpret_cast<const float*>(wsh + (size_t)S_C * piece_n);      // c_q = 2^-t_q
   float* part = a.dq_part + (size_t)split * a.split_stride + (size_t)b * a.batch_stride + (size_t)head * D * L;
   float* kout = a.dqkv + ((size_t)b * 3 * C + (size_t)C + (size_t)head * D) * L;
   float* vout = kout + (size_t)C * L;
@@ -259,54 +331,58 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
   const int nkb_total = L / KB;
   const int kb_begin = split * a.kb_per_split;
   const int kb_end = (kb_begin + a.kb_per_split < nkb_total) ? kb_begin + a.kb_per_split : nkb_total;
-  // the powers of two of this (sample, head): dO' = dO 2^so, V' = V 2^sv
-  const int so = scale_exp(a.absmax[((size_t)b * heads + head) * 2 + 1]), sv = scale_exp(a.absmax[((size_t)b * heads + head) * 2]);
-  const float dscale = __builtin_ldexpf(1.0f, so + sv);      // delta' = delta 2^(so + sv)
+  // the powers of two of this (sample, head): dO' = dO 2^so, V' = V 2^sv, k = K 2^bal, q = Q qscale 2^-bal
+  const unsigned* mx = a.absmax + ((size_t)b * heads + head) * M_COUNT;
+  const int so = scale_exp_o(mx[M_O]), sv = scale_exp_v(mx[M_V]), sq = scale_exp_q(mx[M_Q]), bal = balance_exp(mx[M_Q], mx[M_K], a.qscale);
+  const float dscale_o = __builtin_ldexpf(1.0f, so), dscale_v = __builtin_ldexpf(1.0f, sv);      // delta' = delta 2^so 2^sv (two factors: each a finite float)
   const float one = a.one;
+  const float dnb = __builtin_ldexpf(1.0f, -PAIR_SHIFT);     // a + b 2^-8
+  const float dsdn = __builtin_ldexpf(one, -DS_DOWN<D>);        // dS' = P' (dP' - delta') 2^-DS_DOWN
+  const float up8 = __builtin_ldexpf(one, PAIR_SHIFT);
 
   // contraction slots of this lane in the d-contracted products.  d 16: 8 consecutive d of one of the MFMA's two terms;
   // d 32: 8 consecutive d of the one term
   const int doff = (D == 16) ? 8 * (g & 1) : 8 * g;
   const bool hi = (D == 16) && (g >> 1);
 
-  // ---- staging of one query tile: 640 chunks of 16 bytes (three row pieces of Q, two of dO), three per thread -- the spare
-  // half round repeats dO chunks; 14 - lse2 and -delta' by the first 2 TQ threads
-  unsigned goff[3];
-  int lds_off[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    int c = i * THREADS + tid;
-    if (c >= 640) c -= 128;
-    const int sel = c / 384, cv = c - sel * 384;           // 0: Q rows, 1: dO rows
-    const int p = cv >> 7, rem = cv & 127;
+  // ---- staging of one query tile: 1024 chunks of 16 bytes (two row pieces each of Q, of q c_q, of dO per query and of dO per head), four per thread;
+  // 14 - lse2, -delta' and c_q of the tile's queries by the first TQ threads
+  // chunk i of a thread belongs to block i: one thread-dependent offset on each side
+  static_assert(THREADS == 256, "one chunk of each block per thread");
+  unsigned goff0;
+  int lds_off0;
+  {
+    const int p = tid >> 7, rem = tid & 127;
     const int row = rem / CPR, ch = rem % CPR;
-    goff[i] = (unsigned)(((sel == 0 ? T_QA : T_OA) * 3 + p) * piece_n * 2) + row * GROW + ch * 16;
-    lds_off[i] = (sel == 0 ? QA_OFF : OA_OFF) + p * RPART + row * RROW + ch * 16;
+    goff0 = (unsigned)(p * piece_n * 2) + row * GROW + ch * 16;
+    lds_off0 = p * RPART + row * RROW + ch * 16;
   }
+  constexpr int NST = 4;
+  constexpr int sblock[NST] = {S_Q, S_QE, S_O, S_OH};
+  constexpr int lblock[NST] = {QA_OFF, QE_OFF, OA_OFF, OH_OFF};
   const unsigned char* wsb = reinterpret_cast<const unsigned char*>(wsh);
-  const float* ldsrc = (tid < TQ) ? lbase + tid : dbase + (tid & (TQ - 1));     // used by the first 2 TQ threads only
-  u32x4 stage[3];
-  float stage_ld = 0.f;
+  u32x4 stage[NST];
+  float stage_l = 0.f, stage_d = 0.f, stage_c = 1.f;
   auto stage_load = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) stage[i] = *reinterpret_cast<const u32x4*>(wsb + goff[i] + (size_t)t * (TQ * GROW));
-    if (tid < 2 * TQ) stage_ld = ldsrc[t * TQ];      // negated when stored: nothing here may consume a load at once
+    for (int i = 0; i < NST; ++i) stage[i] = *reinterpret_cast<const u32x4*>(wsb + (size_t)sblock[i] * (piece_n * 2) + goff0 + (size_t)t * (TQ * GROW));
+    if (tid < TQ) { stage_l = lbase[t * TQ + tid]; stage_d = dbase[t * TQ + tid]; stage_c = cbase[t * TQ + tid]; }      // consumed when stored
   };
   auto stage_store = [&](int buf) {
     unsigned char* tb = smem + buf * BUFB;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(tb + lds_off[i]) = stage[i];
-    if (tid < 2 * TQ) *reinterpret_cast<float*>(tb + SL_OFF + tid * 4) = (tid < TQ) ? 14.0f - stage_ld : -stage_ld * dscale;    // sL then sD, contiguous
+    for (int i = 0; i < NST; ++i) *reinterpret_cast<u32x4*>(tb + lblock[i] + lds_off0) = stage[i];
+    if (tid < TQ) {
+      *reinterpret_cast<float*>(tb + SL_OFF + tid * 4) = (float)P_UP - stage_l;
+      *reinterpret_cast<float*>(tb + SD_OFF + tid * 4) = ((-stage_d * dscale_o) * dscale_v) / stage_c;      // delta'_q = delta_q 2^(so + t_q + sv): c_q is a power of two
+      *reinterpret_cast<float*>(tb + SC_OFF + tid * 4) = stage_c;
+    }
   };
 
   // operand addresses inside a tile buffer
-  int a1addr[NOP];      // row reads: (d 16) the term's piece of this lane half / (d 32) piece j; row i16, 16 bytes at doff
+  int a1addr[NA];       // row reads (Q and dO alike, + QA_OFF / OA_OFF): (d 16) the piece of this lane half / (d 32) piece j; row i16, 16 bytes at doff
 #pragma unroll
-  for (int j = 0; j < NOP; ++j)
-    a1addr[j] = ((D == 16) ? (hi ? TERM_B[2 * j + 1] : TERM_B[2 * j]) : j) * RPART + i16 * RROW + doff * 2;
-  int o1addr[NOA];      // dO rows: (d 16) piece 0 in the low half of the contraction, piece 1 in the high half / (d 32) piece j
-#pragma unroll
-  for (int j = 0; j < NOA; ++j) o1addr[j] = ((D == 16) ? (hi ? 1 : 0) : j) * RPART + i16 * RROW + doff * 2;
+  for (int j = 0; j < NA; ++j) a1addr[j] = ((D == 16) ? (hi ? 1 : 0) : j) * RPART + i16 * RROW + doff * 2;
   // transposed reads of the same tiles (A operands of the products that sum over queries): lane 4q + p of a 16-lane group
   // addresses row 4g + q (then 16 + 4g + q), columns d = 16 mt + 4p .. + 3
   const int a3addr = (4 * g + (i16 >> 2)) * RROW + 8 * (i16 & 3);
@@ -315,37 +391,40 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
   // the dS image of this wave: [piece][key 0..31][SROW bytes of 32 queries]
   const int swaddr = i16 * SROW + 8 * g;                              // + piece * SPART + kt * 16 * SROW + jq * 32
   const int sraddr = (8 * g + (i16 >> 2)) * SROW + 8 * (i16 & 3);     // + piece * SPART + jq * 32 (+ 4 * SROW: second half)
-  // reduction of the tile's dQ over the four waves: thread = floats tid, 256 + tid, 512 + tid, 768 + tid of the tile's
-  // [D][TQ] block (1024 floats either way) -- every slab instruction of a wave then covers 256 contiguous bytes (with four
-  // NEIGHBOURING floats per thread the four L2 adds of a wave hit the same eight lines back to back: 95 ms of a 225 ms launch)
+  // x 2^-8 of a packed-fp16 operand (asm: written in C, hipcc 7.2 broadcasts word 0 of such a tuple: attention_h2.hip)
+  auto down = [&](const u32x4& x) {
+    unsigned w4[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) asm("v_pk_mul_f16 %0, %1, %2" : "=v"(w4[w]) : "v"(x[w]), "v"(PAIR_DOWN2));
+    return u32x4{w4[0], w4[1], w4[2], w4[3]};
+  };
 
   for (int kb = kb_begin; kb < kb_end; ++kb) {
     const int key0 = kb * KB + wave * 32;
     // ---- stationary operands of the wave's 32 keys, straight from the workspace
-    u32x4 kB[2][NOP], vB[2][NVB], kT[MT][3];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int j = 0; j < NOP; ++j) {
-        const int p = (D == 16) ? (hi ? TERM_A[2 * j + 1] : TERM_A[2 * j]) : j;
-        const size_t off = (size_t)p * piece_n + (size_t)(key0 + kt * 16 + i16) * D + doff;
-        kB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)T_KB * 3 * piece_n + off);
-      }
-#pragma unroll
-      for (int j = 0; j < NVB; ++j)       // piece j of V' for every lane: at d 16 both halves of the contraction carry it
-        vB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)T_VB * 3 * piece_n + (size_t)j * piece_n +
-                                                    (size_t)(key0 + kt * 16 + i16) * D + doff);
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        kT[mt][p] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(T_KT * 3 + p) * piece_n + (size_t)(16 * mt + i16) * L + key0 + 8 * g);
-    f32x4 dKt[2][MT], dVt[2][MT];
+    u32x4 kB[2][NT], vB[2][NT], kT[MT][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) { dKt[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVt[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int j = 0; j < NT; ++j) {
+        const int p = (D == 16) ? 2 * j + (hi ? 1 : 0) : j;         // pieces (y0, y0 2^-8, y1 2^8, y1)
+        const size_t off = (size_t)p * piece_n + (size_t)(key0 + kt * 16 + i16) * D + doff;
+        kB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)S_K * piece_n + off);
+        vB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)S_V * piece_n + off);
+      }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        kT[mt][p] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_KT + p) * piece_n + (size_t)(16 * mt + i16) * L + key0 + 8 * g);
+    f32x4 dKa[2][MT], dVa[2][MT];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        dKa[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dVa[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 
     __syncthreads();              // the previous key block's last tile is fully consumed
     stage_load(0);
@@ -367,13 +446,16 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub) {
         const unsigned char* sb = tb + sub * 32 * RROW;
-        u32x4 qA[2][NOP], oA[2][NOA];
+        u32x4 qA[2][NT], oA[2][NT];          // [.][0 .. NA - 1] read, [.][NA ..] = those times 2^-8
 #pragma unroll
         for (int jq = 0; jq < 2; ++jq) {
 #pragma unroll
-          for (int j = 0; j < NOP; ++j) qA[jq][j] = *reinterpret_cast<const u32x4*>(sb + QA_OFF + a1addr[j] + jq * 16 * RROW);
+          for (int j = 0; j < NA; ++j) {
+            qA[jq][j] = *reinterpret_cast<const u32x4*>(sb + QA_OFF + a1addr[j] + jq * 16 * RROW);
+            oA[jq][j] = *reinterpret_cast<const u32x4*>(sb + OA_OFF + a1addr[j] + jq * 16 * RROW);
+          }
 #pragma unroll
-          for (int j = 0; j < NOA; ++j) oA[jq][j] = *reinterpret_cast<const u32x4*>(sb + OA_OFF + o1addr[j] + jq * 16 * RROW);
+          for (int j = NA; j < NT; ++j) { qA[jq][j] = down(qA[jq][j - NA]); oA[jq][j] = down(oA[jq][j - NA]); }
         }
         f32x4 negl[2], negd[2];
 #pragma unroll
@@ -381,51 +463,41 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
           negl[jq] = *reinterpret_cast<const f32x4*>(tb + SL_OFF + (32 * sub + 16 * jq + 4 * g) * 4);
           negd[jq] = *reinterpret_cast<const f32x4*>(tb + SD_OFF + (32 * sub + 16 * jq + 4 * g) * 4);
         }
-        // A operands of the q-summed products for M tile mt: dO^T / Q^T rows d = 16 mt .., 32 queries along the contraction
-        auto load_transposed = [&](int mt, u32x4 (&qT)[3], u32x4 (&oT)[2]) {
+        // A operands of the q-summed products for M tile mt: dO'^T / (q c_q)^T rows d = 16 mt .., 32 queries along the contraction;
+        // piece 0 = x0, piece 1 = x1 2^8
+        auto load_transposed = [&](int mt, u32x4 (&qT)[2], u32x4 (&oT)[2]) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            const unsigned char* sq = sb + QA_OFF + p * RPART + a3addr + 32 * mt;
+          for (int p = 0; p < 2; ++p) {
+            const unsigned char* sq = sb + QE_OFF + p * RPART + a3addr + 32 * mt;      // q c_q
             const u32x2 q0 = lds_read_tr16(sq), q1 = lds_read_tr16(sq + 16 * RROW);
             qT[p] = u32x4{q0[0], q0[1], q1[0], q1[1]};
-            if (p < 2) {
-              const unsigned char* sop = sb + OA_OFF + p * RPART + a3addr + 32 * mt;
-              const u32x2 o0 = lds_read_tr16(sop), o1 = lds_read_tr16(sop + 16 * RROW);
-              oT[p] = u32x4{o0[0], o0[1], o1[0], o1[1]};
-            }
+            const unsigned char* sop = sb + OH_OFF + p * RPART + a3addr + 32 * mt;      // dO 2^so
+            const u32x2 o0 = lds_read_tr16(sop), o1 = lds_read_tr16(sop + 16 * RROW);
+            oT[p] = u32x4{o0[0], o0[1], o1[0], o1[1]};
           }
         };
-        u32x4 qT0[3], oT0[2];
+        u32x4 qT0[2], oT0[2];
         if (MT == 1) load_transposed(0, qT0, oT0);       // d 16: read once per subtile, used by both key tiles
 
+        // term order of the four-term products: d 16 -- MFMA j = A_j B_j; d 32 -- (x0, y0), (x1 2^8, y0 2^-8), (x0 2^-8, y1 2^8), (x1, y1):
+        // row operand index {0, 1, 2, 3} = x0, x1 2^8, x0 2^-8, x1; stationary piece index {0, 1, 2, 3} = y0, y0 2^-8, y1 2^8, y1
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
           f32x4 S[2], dP[2];
 #pragma unroll
           for (int jq = 0; jq < 2; ++jq) {
             f32x4 acc = negl[jq];
-            if constexpr (D == 16) {
 #pragma unroll
-              for (int j = 0; j < 3; ++j) acc = mfma_bf16(qA[jq][j], kB[kt][j], acc);
-            } else {
-#pragma unroll
-              for (int term = 5; term >= 0; --term) acc = mfma_bf16(qA[jq][TERM_B[term]], kB[kt][TERM_A[term]], acc);
-            }
+            for (int j = 0; j < NT; ++j) acc = mfma_f16(qA[jq][j], kB[kt][j], acc);          // large term first
             S[jq] = acc;
             acc = negd[jq];
-            // (mutation test, bit 16: the cross product o0 v1 dropped -- at d 16 with its MFMA partner o1 v1, a 2^-22 term)
-            if constexpr (D == 16) {        // (o0 v1 + o1 v1), then (o0 v0 + o1 v0): the small products first
-              if (!(HDIFF_MUTANT & 16)) acc = mfma_f16(oA[jq][0], vB[kt][1], acc);
-              acc = mfma_f16(oA[jq][0], vB[kt][0], acc);
-            } else {
-              acc = mfma_f16(oA[jq][1], vB[kt][1], acc);
-              if (!(HDIFF_MUTANT & 16)) acc = mfma_f16(oA[jq][0], vB[kt][1], acc);
-              acc = mfma_f16(oA[jq][1], vB[kt][0], acc);
-              acc = mfma_f16(oA[jq][0], vB[kt][0], acc);
-            }
+            // (mutation test, bit 16: the cross product o0 v1 dropped -- with its MFMA partner o1 v1 at d 16)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              if (!((HDIFF_MUTANT & 16) && j == (D == 16 ? 1 : 2))) acc = mfma_f16(oA[jq][j], vB[kt][j], acc);
             dP[jq] = acc;
           }
-          u32x4 Pp[2], Sp[3];
+          u32x4 Pp[2], Sp[2];
 #pragma unroll
           for (int jq = 0; jq < 2; ++jq) {
             float p[4], ds[4];
@@ -438,39 +510,40 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
 #pragma unroll
               for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
-                  if (pc < 2) Pp[pc][2 * jq + h] = __builtin_bit_cast(unsigned, S[jq][2 * h]) + pc;
+                for (int pc = 0; pc < 2; ++pc) {
+                  Pp[pc][2 * jq + h] = __builtin_bit_cast(unsigned, S[jq][2 * h]) + pc;
                   Sp[pc][2 * jq + h] = __builtin_bit_cast(unsigned, dP[jq][2 * h + 1]) + pc;
                 }
             } else {
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                unsigned h0, h1, h2;
-                split2(p[2 * h], p[2 * h + 1], one, h0, h1);
-                Pp[0][2 * jq + h] = h0; Pp[1][2 * jq + h] = h1;
-                split3(ds[2 * h], ds[2 * h + 1], h0, h1, h2);
-                Sp[0][2 * jq + h] = h0; Sp[1][2 * jq + h] = h1; Sp[2][2 * jq + h] = h2;
-              }
+              unsigned sa0, sa1, sb0, sb1;
+              split2_scaled(ds[0], ds[1], ds[2], ds[3], dsdn, up8, sa0, sa1, sb0, sb1);
+              if (HDIFF_MUTANT & 64) { sa1 &= 0xffe0ffe0u; sb1 &= 0xffe0ffe0u; }      // (mutation test, bit 64: the low five bits of the second piece of dS': 2^-17 of dS)
+              Sp[0][2 * jq] = sa0; Sp[1][2 * jq] = sa1; Sp[0][2 * jq + 1] = sb0; Sp[1][2 * jq + 1] = sb1;
+              unsigned pa0, pa1, pb0, pb1;
+              split2(p[0], p[1], one, pa0, pa1);
+              split2(p[2], p[3], one, pb0, pb1);
+              Pp[0][2 * jq] = pa0; Pp[1][2 * jq] = pa1; Pp[0][2 * jq + 1] = pb0; Pp[1][2 * jq + 1] = pb1;
             }
             // the packed dS pieces of (key i16 of tile kt, queries 16 jq + 4g ..+3) into the wave's [key][query] image
             if (!(H2B_ABL & 4)) {
 #pragma unroll
-              for (int pc = 0; pc < 3; ++pc)
+              for (int pc = 0; pc < 2; ++pc)
                 *reinterpret_cast<u32x2*>(scr + pc * SPART + kt * 16 * SROW + jq * 32 + swaddr) = u32x2{Sp[pc][2 * jq], Sp[pc][2 * jq + 1]};
             }
           }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            u32x4 qTm[3], oTm[2];
+            u32x4 qTm[2], oTm[2];
             if (MT > 1) load_transposed(mt, qTm, oTm);       // d 32: one M tile's operands at a time (registers)
-#pragma unroll
-            for (int term = 5; term >= 0; --term) {      // small terms first
-              // (mutation test, bit 32: the product o1 p0 of dV^T dropped; bit 64: the 2^-16 term q0 s2 of dK^T -- and k0 s2 of dQ^T below)
-              if (term < 3 && !((HDIFF_MUTANT & 32) && term == 1))
-                dVt[kt][mt] = mfma_f16((MT == 1 ? oT0 : oTm)[TERM_A[term]], Pp[TERM_B[term]], dVt[kt][mt]);   // o0 p1, o1 p0, o0 p0
-              if (!((HDIFF_MUTANT & 64) && term == 5))
-                dKt[kt][mt] = mfma_bf16((MT == 1 ? qT0 : qTm)[TERM_A[term]], Sp[TERM_B[term]], dKt[kt][mt]);
-            }
+            const u32x4 (&qT)[2] = (MT == 1 ? qT0 : qTm);
+            const u32x4 (&oT)[2] = (MT == 1 ? oT0 : oTm);
+            // small terms first; (mutation test, bit 32: the product o1 p0 of dV^T dropped)
+            if (!(HDIFF_MUTANT & 32)) dVa[kt][mt] = mfma_f16(oT[1], Pp[0], dVa[kt][mt]);        // o1 p0
+            dVa[kt][mt] = mfma_f16(oT[0], Pp[1], dVa[kt][mt]);        // o0 p1
+            dVa[kt][mt] = mfma_f16(oT[0], Pp[0], dVa[kt][mt]);        // o0 p0
+            dKa[kt][mt] = mfma_f16(qT[1], Sp[0], dKa[kt][mt]);        // q1 s0
+            dKa[kt][mt] = mfma_f16(down(qT[0]), Sp[1], dKa[kt][mt]);  // (q0 2^-8) (s1 2^8)
+            dKa[kt][mt] = mfma_f16(qT[0], Sp[0], dKa[kt][mt]);        // q0 s0
           }
         }
 
@@ -478,20 +551,21 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int jq = 0; jq < 2; ++jq) {
-          u32x4 sT[3];
+          u32x4 sT[2];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < 2; ++p) {
             const unsigned char* src = scr + p * SPART + jq * 32 + sraddr;
             const u32x2 lo = lds_read_tr16(src), hi2 = lds_read_tr16(src + 4 * SROW);
             sT[p] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
           }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f}, accb = f32x4{0.f, 0.f, 0.f, 0.f};
+            acca = mfma_f16(kT[mt][0], sT[0], acca);        // k0 s0
+            accb = mfma_f16(kT[mt][1], sT[0], accb);        // (k1 2^8) s0
+            accb = mfma_f16(kT[mt][0], sT[1], accb);        // k0 (s1 2^8)
 #pragma unroll
-            for (int term = 5; term >= 0; --term)
-              if (!((HDIFF_MUTANT & 64) && term == 5)) acc = mfma_bf16(kT[mt][TERM_A[term]], sT[TERM_B[term]], acc);
-            dQt[sub][jq][mt] = acc;
+            for (int r = 0; r < 4; ++r) dQt[sub][jq][mt][r] = __builtin_fmaf(accb[r], dnb, acca[r]);
           }
         }
         asm volatile("" ::: "memory");      // the next subtile's image stores stay behind these reads (same wave: in order)
@@ -521,7 +595,8 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
           float v = s0[0];
 #pragma unroll
           for (int w = 1; w < 4; ++w) v += s0[w * (SCRB / 4)];
-          sum[r] = __builtin_ldexpf(v * a.inv_sqrt_d, -(14 + so + sv));
+          // Y = dQ_q sqrt(d) 2^(bal + so + t_q + sv + 14 - DS_DOWN)
+          sum[r] = __builtin_ldexpf(v * a.inv_sqrt_d, -(P_UP - DS_DOWN<D> + so + sv + bal)) * *reinterpret_cast<const float*>(tb + SC_OFF + (e % TQ) * 4);
         }
         // tile t + 1 into LDS, then the loads of tile t + 2
         stage_store(buf ^ 1);
@@ -539,7 +614,8 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
       lds_barrier();
     }
 
-    // ---- dK, dV of this key block (complete: the sweep covered every query).  dK carries Q pre-scaled by log2(e)/sqrt(d)
+    // ---- dK, dV of this key block (complete: the sweep covered every query).  X = dK sqrt(d) 2^(sq + so + sv + 14 - DS_DOWN) (the rows of Q 2^sq c_q),
+    // Z = dV 2^(14 + so)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       const int key = key0 + kt * 16 + i16;
@@ -548,8 +624,8 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int d = 16 * mt + 4 * g + r;
-          kout[(size_t)d * L + key] = __builtin_ldexpf(dKt[kt][mt][r] * 0.6931471805599453f, -(14 + so + sv));
-          vout[(size_t)d * L + key] = __builtin_ldexpf(dVt[kt][mt][r], -(14 + so));
+          kout[(size_t)d * L + key] = __builtin_ldexpf(dKa[kt][mt][r] * a.inv_sqrt_d, -(P_UP - DS_DOWN<D> + so + sv + sq));
+          vout[(size_t)d * L + key] = __builtin_ldexpf(dVa[kt][mt][r], -(P_UP + so));
         }
     }
   }
@@ -627,12 +703,11 @@ bool mha_bwd_x3_applicable(int B, int C, int heads, int L) {
 }
 
 // slabs (tile-major, one per key range: even a single range goes through the reduce kernel, which restores the [C][L] layout)
-// followed by the piece tensors (fifteen 2-byte piece slots per element: the layout round 3's bf16-triple kernel introduced; the V
-// and dO tensors fill two of their three) and the B * heads * 2 tensor maxima, in floats
+// followed by the piece tensors (fifteen 2-byte piece slots per element, fourteen of them used) and the B * heads * 4 tensor maxima, in floats
 int64_t mha_bwd_x3_workspace_floats(int B, int C, int heads, int L) {
   const H2Geom g = h2_geometry(B, heads, L, C / heads);
-  const int64_t pieces_bytes = (int64_t)B * C * L * (T_COUNT * 3) * 2;
-  return (int64_t)g.nsplit * B * C * L + (pieces_bytes + 3) / 4 + 4 + (int64_t)B * heads * 2 + 4;
+  const int64_t pieces_bytes = (int64_t)B * C * L * S_COUNT * 2;
+  return (int64_t)g.nsplit * B * C * L + (pieces_bytes + 3) / 4 + 4 + (int64_t)B * heads * M_COUNT + 4;
 }
 
 // delta has been computed by the caller (mha_delta_kernel)
@@ -645,18 +720,19 @@ void launch_mha_bwd_h2(const float* qkv, const float* d_o, const float* lse2, co
   uintptr_t pw = reinterpret_cast<uintptr_t>(ws + slab);
   pw = (pw + 15) & ~(uintptr_t)15;
   __bf16* pieces = reinterpret_cast<__bf16*>(pw);
-  unsigned* absmax = reinterpret_cast<unsigned*>(pieces + (size_t)B * C * L * (T_COUNT * 3));      // 4-byte aligned: the pieces are a multiple of 4 bytes
+  unsigned* absmax = reinterpret_cast<unsigned*>(pieces + (size_t)B * C * L * S_COUNT);      // 4-byte aligned: the pieces are a multiple of 4 bytes
   BwdH2Args a;
   a.ws = pieces; a.lse2 = lse2; a.delta = delta; a.dqkv = dqkv;
   a.C = C; a.L = L; a.kb_per_split = g.per;
   a.inv_sqrt_d = 1.0f / sqrtf((float)D);
+  a.qscale = 1.4426950408889634f * a.inv_sqrt_d;
   a.dq_part = ws; a.split_stride = (size_t)B * per_sample; a.batch_stride = per_sample;
   a.absmax = absmax; a.one = 1.0f;
-  const float qscale = 1.4426950408889634f * a.inv_sqrt_d;
-  const dim3 mgrid(cdiv(L, 4096), 2 * heads, B), sgrid(cdiv(L, THREADS), 4 * heads, B), grid(g.nsplit, heads, B);
+  const float qscale = a.qscale;
+  const dim3 mgrid(cdiv(L, 4096), M_COUNT * heads, B), sgrid(cdiv(L, THREADS), 4 * heads, B), grid(g.nsplit, heads, B);
   const size_t n4 = per_sample / 4;
   const int bx = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  (void)hipMemsetAsync(absmax, 0, (size_t)B * heads * 2 * sizeof(unsigned), stream);
+  (void)hipMemsetAsync(absmax, 0, (size_t)B * heads * M_COUNT * sizeof(unsigned), stream);
   if (D == 16) {
     hipLaunchKernelGGL(mha_bwd_absmax_kernel<16>, mgrid, dim3(THREADS), 0, stream, qkv, d_o, absmax, C, L);
     hipLaunchKernelGGL(mha_bwd_split_h2_kernel<16>, sgrid, dim3(THREADS), 0, stream, qkv, d_o, pieces, absmax, C, L, qscale, 1.0f);

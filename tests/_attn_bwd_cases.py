@@ -1,5 +1,5 @@
 """Shared by tests/test_gpu_backward.py and tools/attn_bwd_error_ratio.py: inputs that stress the fp16-pair attention backward
-(attention_bwd_h2.hip scales dO and V by ONE power of two per (sample, head)), a query-chunked float64 reference of one
+(attention_bwd_h2.hip scales V by one power of two per (sample, head), dO by one per head and one per query position), a query-chunked float64 reference of one
 (sample, head) pair, and the error statistics of the split-operand kernel beside the fp32-input kernel's."""
 import ctypes as C
 import math
