@@ -165,7 +165,7 @@ __device__ __forceinline__ int balance_exp(unsigned qmax_bits, unsigned kmax_bit
 // Piece slots of one (sample, head), each L * D fp16: rows of q (q0, q1 2^8); rows of Q 2^sq c_q (x0, x1); rows of k (k0, k0 2^-8,
 // k1 2^8, k1); k transposed [D][L] (k0, k1 2^8); rows of V' (v0, v0 2^-8, v1 2^8, v1); rows of dO scaled per query (o0, o1 2^8); rows of
 // dO scaled per head (x0, x1); the L factors c_q (fp32) in the last slot
-enum { S_Q = 0, S_QE = 2, S_K = 4, S_KT = 8, S_V = 10, S_O = 14, S_OH = 16, S_C = 18, S_COUNT = 19 };
+enum { S_Q = 0, S_QE = 2, S_K = 4, S_KT = 8, S_V = 10, S_O = 12, S_OH = 14, S_C = 16, S_COUNT = 17 };
 enum { M_V = 0, M_O = 1, M_Q = 2, M_K = 3, M_COUNT = 4 };      // maxima per (sample, head)
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -244,13 +244,13 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_split_h2_kernel(const float* 
 #pragma unroll
     for (int j = 0; j < D / 2; ++j)
       pair4(src[(size_t)(2 * j) * L + l] * scq, src[(size_t)(2 * j + 1) * L + l] * scq, up, h[0][j], h[1][j], h[2][j], h[3][j]);
-    // Q, dO: (x0, x1 2^8); K, V: all four
+    // q: (x0, x1 2^8); k: all four; V', dO' (maxima in [2^13, 2^14): form (ii)): (x0, x1)
     const int slot0 = which == 0 ? S_Q : which == 1 ? S_K : which == 2 ? S_V : S_O;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const bool two = (which == 0 || which == 3);
-      if (two && (p == 1 || p == 3)) continue;
-      const int slot = slot0 + (two ? (p == 0 ? 0 : 1) : p);
+      if (which == 0 && (p == 1 || p == 3)) continue;
+      if (which >= 2 && (p == 1 || p == 2)) continue;
+      const int slot = slot0 + (which == 1 ? p : (p == 0 ? 0 : 1));
       u32x4* o = reinterpret_cast<u32x4*>(base + (size_t)slot * piece + (size_t)l * D);
 #pragma unroll
       for (int j = 0; j < D / 8; ++j) o[j] = u32x4{h[p][4 * j], h[p][4 * j + 1], h[p][4 * j + 2], h[p][4 * j + 3]};
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
   for (int kb = kb_begin; kb < kb_end; ++kb) {
     const int key0 = kb * KB + wave * 32;
     // ---- stationary operands of the wave's 32 keys, straight from the workspace
-    u32x4 kB[2][NT], vB[2][NT], kT[MT][2];
+    u32x4 kB[2][NT], vB[2][2], kT[MT][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -410,8 +410,13 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
         const int p = (D == 16) ? 2 * j + (hi ? 1 : 0) : j;         // pieces (y0, y0 2^-8, y1 2^8, y1)
         const size_t off = (size_t)p * piece_n + (size_t)(key0 + kt * 16 + i16) * D + doff;
         kB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)S_K * piece_n + off);
-        vB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)S_V * piece_n + off);
       }
+    // V' pieces (v0, v1), form (ii): d 16 -- MFMA j = (o0 | o1)(v_j | v_j); d 32 -- o0 v0, o1 v0, o0 v1
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        vB[kt][p] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_V + p) * piece_n + (size_t)(key0 + kt * 16 + i16) * D + doff);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
             oA[jq][j] = *reinterpret_cast<const u32x4*>(sb + OA_OFF + a1addr[j] + jq * 16 * RROW);
           }
 #pragma unroll
-          for (int j = NA; j < NT; ++j) { qA[jq][j] = down(qA[jq][j - NA]); oA[jq][j] = down(oA[jq][j - NA]); }
+          for (int j = NA; j < NT; ++j) { qA[jq][j] = down(qA[jq][j - NA]); oA[jq][j] = oA[jq][j - NA]; }      // dO', V': no shifts (form (ii))
         }
         f32x4 negl[2], negd[2];
 #pragma unroll
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
             // (mutation test, bit 16: the cross product o0 v1 dropped -- with its MFMA partner o1 v1 at d 16)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-              if (!((HDIFF_MUTANT & 16) && j == (D == 16 ? 1 : 2))) acc = mfma_f16(oA[jq][j], vB[kt][j], acc);
+              if (!((HDIFF_MUTANT & 16) && j == (D == 16 ? 1 : 2))) acc = mfma_f16(oA[jq][j], vB[kt][D == 16 ? j : j >> 1], acc);
             dP[jq] = acc;
           }
           u32x4 Pp[2], Sp[2];
