@@ -43,8 +43,19 @@ namespace {
 #ifndef H2B_ABL
 #define H2B_ABL 0            // dev: timing ablations (bit mask), results are wrong with any bit set
 #endif
-constexpr int THREADS = 256;
-constexpr int KB = 128;                // keys per workgroup block (32 per wave)
+constexpr int THREADS = 256;           // of the preparation kernels
+#ifndef H2B_WAVES
+#define H2B_WAVES 8
+#endif
+#ifndef H2B_WANT
+#define H2B_WANT 1024
+#endif
+// Waves of a main-kernel workgroup, 32 keys each.  EIGHT: one workgroup per CU instead of two of four waves -- every query tile is
+// staged once per 256 keys instead of once per 128, and the workgroup's dQ partial tile (summed over its waves in LDS) goes to the
+// slab once per 256 keys: half the L2 float adds (timing ablation on the four-wave build: the adds were 13 % of the launch).
+constexpr int MW = H2B_WAVES;
+constexpr int MTHREADS = 64 * MW;
+constexpr int KB = 32 * MW;            // keys per workgroup block
 constexpr int SROW = 72;               // bytes per key row of the dS image [key][32 queries] (64 + 8: conflict-free ds_write_b64)
 constexpr int SPART = 32 * SROW;       // 2304 per piece
 constexpr int SCRB = 2 * SPART;        // 4608 per wave (two pieces of dS)
@@ -70,7 +81,8 @@ struct Geo {
   static constexpr int DQS = TQ + 4;                  // row stride (floats) of a wave's dQ partial tile [D][DQS], aliased on its scratch
   static_assert(TQ * GROW == 2048, "staging geometry: 128 chunks per piece");
   static_assert(D * DQS * 4 <= SCRB, "dQ partial tile must fit in the wave's scratch");
-  static_assert(2 * BUFB + 4 * SCRB <= 65536, "static LDS");
+  static constexpr int LDS_BYTES = 2 * BUFB + MW * SCRB;      // dynamic (eight waves: 70 KB)
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -301,7 +313,7 @@ struct BwdH2Args {
 };
 
 template <int D>
-__global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args a) {
+__global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a) {
   using G = Geo<D>;
   constexpr int TQ = G::TQ, NSUB = G::NSUB, MT = G::MT, RROW = G::RROW, GROW = G::GROW, CPR = G::CPR, RPART = G::RPART, BUFB = G::BUFB, DQS = G::DQS;
   constexpr int QA_OFF = G::QA_OFF, QE_OFF = G::QE_OFF, OA_OFF = G::OA_OFF, OH_OFF = G::OH_OFF, SL_OFF = G::SL_OFF, SD_OFF = G::SD_OFF, SC_OFF = G::SC_OFF;
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
   constexpr int NA = (D == 16) ? 1 : 2;        // row operands READ per 16 rows
   constexpr int NT = (D == 16) ? 2 : 3;        // MFMAs of one d-contracted 16x16 tile = stationary operand sets per 16 keys; operands NA .. NT - 1 are
                                                // the first NT - NA read ones times 2^-8
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB + 4 * SCRB];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 * BUFB + MW * SCRB
 
   const int C = a.C, L = a.L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -345,33 +357,36 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
   const int doff = (D == 16) ? 8 * (g & 1) : 8 * g;
   const bool hi = (D == 16) && (g >> 1);
 
-  // ---- staging of one query tile: 1024 chunks of 16 bytes (two row pieces each of Q, of q c_q, of dO per query and of dO per head), four per thread;
+  // ---- staging of one query tile: 1024 chunks of 16 bytes (two row pieces each of Q, of q c_q, of dO per query and of dO per head), two per thread;
   // 14 - lse2, -delta' and c_q of the tile's queries by the first TQ threads
-  // chunk i of a thread belongs to block i: one thread-dependent offset on each side
-  static_assert(THREADS == 256, "one chunk of each block per thread");
+  // the 1024 chunks: blocks {Q, q c_q, dO per query, dO per head} x 2 pieces x 128 chunks; thread tid takes chunk tid + MTHREADS i
+  constexpr int NST = 1024 / MTHREADS;
+  static_assert(MTHREADS == 256 || MTHREADS == 512, "staging geometry");
+  static_assert(S_O - S_Q == S_OH - S_QE && G::OA_OFF - G::QA_OFF == G::OH_OFF - G::QE_OFF, "chunk i + 1 of a thread = chunk i moved by a fixed amount");
   unsigned goff0;
   int lds_off0;
   {
-    const int p = tid >> 7, rem = tid & 127;
+    const int blk = tid >> 8, cv = tid & 255;             // (512 threads) block 0 / 1 for chunk 0, 2 / 3 for chunk 1; (256) block i for chunk i
+    const int p = cv >> 7, rem = cv & 127;
     const int row = rem / CPR, ch = rem % CPR;
-    goff0 = (unsigned)(p * piece_n * 2) + row * GROW + ch * 16;
-    lds_off0 = p * RPART + row * RROW + ch * 16;
+    goff0 = (unsigned)(((blk ? S_QE : S_Q) + p) * piece_n * 2) + row * GROW + ch * 16;
+    lds_off0 = (blk ? QE_OFF : QA_OFF) + p * RPART + row * RROW + ch * 16;
   }
-  constexpr int NST = 4;
-  constexpr int sblock[NST] = {S_Q, S_QE, S_O, S_OH};
-  constexpr int lblock[NST] = {QA_OFF, QE_OFF, OA_OFF, OH_OFF};
+  // chunk i: (512 threads) + i (S_O - S_Q) slots / + i (OA_OFF - QA_OFF); (256 threads) slots S_Q, S_QE, S_O, S_OH in turn
+  auto gslot = [&](int i) -> size_t { return (size_t)(MTHREADS == 512 ? i * (S_O - S_Q) : (i == 0 ? 0 : i == 1 ? S_QE - S_Q : i == 2 ? S_O - S_Q : S_OH - S_Q)) * (piece_n * 2); };
+  auto lslot = [&](int i) { return MTHREADS == 512 ? i * (OA_OFF - QA_OFF) : (i == 0 ? 0 : i == 1 ? QE_OFF : i == 2 ? OA_OFF : OH_OFF); };
   const unsigned char* wsb = reinterpret_cast<const unsigned char*>(wsh);
   u32x4 stage[NST];
   float stage_l = 0.f, stage_d = 0.f, stage_c = 1.f;
   auto stage_load = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < NST; ++i) stage[i] = *reinterpret_cast<const u32x4*>(wsb + (size_t)sblock[i] * (piece_n * 2) + goff0 + (size_t)t * (TQ * GROW));
+    for (int i = 0; i < NST; ++i) stage[i] = *reinterpret_cast<const u32x4*>(wsb + gslot(i) + goff0 + (size_t)t * (TQ * GROW));
     if (tid < TQ) { stage_l = lbase[t * TQ + tid]; stage_d = dbase[t * TQ + tid]; stage_c = cbase[t * TQ + tid]; }      // consumed when stored
   };
   auto stage_store = [&](int buf) {
     unsigned char* tb = smem + buf * BUFB;
 #pragma unroll
-    for (int i = 0; i < NST; ++i) *reinterpret_cast<u32x4*>(tb + lblock[i] + lds_off0) = stage[i];
+    for (int i = 0; i < NST; ++i) *reinterpret_cast<u32x4*>(tb + lslot(i) + lds_off0) = stage[i];
     if (tid < TQ) {
       *reinterpret_cast<float*>(tb + SL_OFF + tid * 4) = (float)P_UP - stage_l;
       *reinterpret_cast<float*>(tb + SD_OFF + tid * 4) = ((-stage_d * dscale_o) * dscale_v) / stage_c;      // delta'_q = delta_q 2^(so + t_q + sv): c_q is a power of two
@@ -591,15 +606,17 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
 #pragma unroll
               for (int r = 0; r < 4; ++r) sdq[(16 * mt + 4 * g + r) * DQS + 32 * sub + 16 * jq + i16] = dQt[sub][jq][mt][r];
         lds_barrier();
-        // thread -> floats tid + 256 r of the [D][TQ] block: row d = e / TQ, query e % TQ
-        f32x4 sum;
+        // thread -> floats tid + MTHREADS r of the [D][TQ] block: row d = e / TQ, query e % TQ
+        constexpr int NR = 1024 / MTHREADS;
+        static_assert(D * TQ == 1024, "slab tile");
+        float sum[NR];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int e = tid + 256 * r;
+        for (int r = 0; r < NR; ++r) {
+          const int e = tid + MTHREADS * r;
           const float* s0 = reinterpret_cast<const float*>(smem + 2 * BUFB) + (e / TQ) * DQS + (e % TQ);
           float v = s0[0];
 #pragma unroll
-          for (int w = 1; w < 4; ++w) v += s0[w * (SCRB / 4)];
+          for (int w = 1; w < MW; ++w) v += s0[w * (SCRB / 4)];
           // Y = dQ_q sqrt(d) 2^(bal + so + t_q + sv + 14 - DS_DOWN)
           sum[r] = __builtin_ldexpf(v * a.inv_sqrt_d, -(P_UP - DS_DOWN<D> + so + sv + bal)) * *reinterpret_cast<const float*>(tb + SC_OFF + (e % TQ) * 4);
         }
@@ -609,10 +626,10 @@ __global__ __launch_bounds__(THREADS, 2) void mha_bwd_h2_kernel(const BwdH2Args 
         if (!(H2B_ABL & 65) || t == 0) {
           if (first_kb) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pdst[256 * r] = sum[r];
+            for (int r = 0; r < NR; ++r) pdst[MTHREADS * r] = sum[r];
           } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) unsafeAtomicAdd(pdst + 256 * r, sum[r]);
+            for (int r = 0; r < NR; ++r) unsafeAtomicAdd(pdst + MTHREADS * r, sum[r]);
           }
         }
       }
@@ -663,7 +680,7 @@ struct H2Geom { int nkb_total, per, nsplit; };
 H2Geom h2_geometry(int B, int heads, int L, int D) {
   H2Geom g;
   g.nkb_total = L / KB;
-  int want = cdiv(1024, B * heads);                      // ~2 rounds of 2 workgroups per CU on 256 CUs
+  int want = cdiv(H2B_WANT, B * heads);                  // workgroups wanted in all: four rounds of one per CU on 256 CUs
   // At larger batches that leaves few key ranges per (sample, head) pair, and the workgroups of a pair are the ones that share
   // its Q / dO tile stream in their XCD's L2: up to 16 ranges per pair (batch 16: 567 -> 553 ms per launch; 32: 547) as
   // long as the slabs stay below the cap (16 GiB, or HDIFF_BWD_SLAB_GIB: mha_bwd_slab_cap_bytes).
@@ -701,7 +718,7 @@ long long mha_bwd_slab_cap_bytes() {
 // slab reduce cost more than the matrix core gains (56 vs 47 us at B = 1, L = 1024; 0.62 vs 0.94 ms at B = 4, L = 4096)
 bool mha_bwd_x3_shape_ok(int B, int C, int heads, int L) {
   const int D = C / heads;
-  return C % heads == 0 && (D == 16 || D == 32) && L % 256 == 0 && L >= 512 && (int64_t)B * heads * (L / KB) >= 256;
+  return C % heads == 0 && (D == 16 || D == 32) && L % 256 == 0 && L >= 512 && (int64_t)B * heads * (L / 128) >= 256;
 }
 bool mha_bwd_x3_applicable(int B, int C, int heads, int L) {
   return contraction_mode() == HDIFF_CONTRACT_BF16X3 && mha_bwd_x3_shape_ok(B, C, heads, L);
@@ -738,15 +755,20 @@ void launch_mha_bwd_h2(const float* qkv, const float* d_o, const float* lse2, co
   const size_t n4 = per_sample / 4;
   const int bx = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   (void)hipMemsetAsync(absmax, 0, (size_t)B * heads * M_COUNT * sizeof(unsigned), stream);
+  static const bool lds_ok = [] {      // more than 64 KB of LDS per workgroup has to be asked for, once per process
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_bwd_h2_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<16>::LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_bwd_h2_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES) == hipSuccess;
+  }();
+  (void)lds_ok;
   if (D == 16) {
     hipLaunchKernelGGL(mha_bwd_absmax_kernel<16>, mgrid, dim3(THREADS), 0, stream, qkv, d_o, absmax, C, L);
     hipLaunchKernelGGL(mha_bwd_split_h2_kernel<16>, sgrid, dim3(THREADS), 0, stream, qkv, d_o, pieces, absmax, C, L, qscale, 1.0f);
-    hipLaunchKernelGGL(mha_bwd_h2_kernel<16>, grid, dim3(THREADS), 0, stream, a);
+    hipLaunchKernelGGL(mha_bwd_h2_kernel<16>, grid, dim3(MTHREADS), Geo<16>::LDS_BYTES, stream, a);
     hipLaunchKernelGGL(mha_dq_reduce_h2_kernel<16>, dim3(bx, B), dim3(256), 0, stream, ws, dqkv, g.nsplit, C, L, a.split_stride);
   } else {
     hipLaunchKernelGGL(mha_bwd_absmax_kernel<32>, mgrid, dim3(THREADS), 0, stream, qkv, d_o, absmax, C, L);
     hipLaunchKernelGGL(mha_bwd_split_h2_kernel<32>, sgrid, dim3(THREADS), 0, stream, qkv, d_o, pieces, absmax, C, L, qscale, 1.0f);
-    hipLaunchKernelGGL(mha_bwd_h2_kernel<32>, grid, dim3(THREADS), 0, stream, a);
+    hipLaunchKernelGGL(mha_bwd_h2_kernel<32>, grid, dim3(MTHREADS), Geo<32>::LDS_BYTES, stream, a);
     hipLaunchKernelGGL(mha_dq_reduce_h2_kernel<32>, dim3(bx, B), dim3(256), 0, stream, ws, dqkv, g.nsplit, C, L, a.split_stride);
   }
 }
