@@ -599,9 +599,10 @@ def main():
                            "state_abs_max": x_timed.abs().max().item(), "state_rms": x_timed.double().pow(2).mean().sqrt().item()}
             alt = {"contract": other, "ms_per_step": dt_alt * 1e3, "denoising_steps_per_s": 1.0 / dt_alt,
                    "note": "same workload with the attention / 3x3-conv contractions in the other mode (plain launches); "
-                           "f32 = fp32-input MFMA (exact k-ordered fma chain); bf16x3 = every fp32 operand as three bf16 "
-                           "pieces, six products on the bf16 MFMA, fp32 accumulate (fp32-class error, "
-                           "tests/test_gpu_ops.py::test_flash_attention_split_bf16_is_fp32_class)"}
+                           "f32 = fp32-input MFMA (exact k-ordered fma chain); bf16x3 = the split-operand mode (the name is "
+                           "round 3's): every fp32 operand as 16-bit pieces -- fp16 pairs where its range is known or "
+                           "balanced per product term, bf16 triples elsewhere --, products on the 16-bit MFMA, fp32 "
+                           "accumulate (fp32-class error, tests/test_gpu_ops.py::test_flash_attention_split_bf16_is_fp32_class)"}
 
     if dist:
         tmax = torch.tensor([elapsed], device="cpu" if a.rehearse_one_gpu else dev, dtype=torch.float64)

@@ -316,8 +316,9 @@ def _flash(lib, qkv, heads, want_lse=False, workspace=False):
 @pytest.mark.parametrize("workspace", [False, True], ids=["split-in-loop", "pre-split"])
 @pytest.mark.parametrize("d,L,B,scale", [(16, 1024, 2, 1.0), (16, 4096, 1, 3.0), (32, 2048, 1, 1.0), (32, 512, 2, 2.0)])
 def test_flash_attention_split_bf16_is_fp32_class(d, L, B, scale, workspace, bf16x3_mode):
-    """HDIFF_CONTRACT_BF16X3: fp32 operands as three bf16 pieces, six products on the bf16 MFMA.  Claim checked here: its
-    error against float64 is of the same class as the fp32-MFMA kernel's (not merely inside the tolerance)."""
+    """HDIFF_CONTRACT_BF16X3, the split-operand mode: fp32 operands as 16-bit pieces on the 16-bit MFMA -- with a workspace the fp16-pair
+    kernels (attention_h2.hip at d_head 16, attention_x3p.hip at 32), without one the in-loop bf16-triple kernel (attention_x3.hip).
+    Claim checked here: the error against float64 is of the same class as the fp32-MFMA kernel's (not merely inside the tolerance)."""
     lib = bf16x3_mode
     g = torch.Generator().manual_seed(100 + d + L)
     heads = 8
