@@ -624,7 +624,7 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
         stage_store(buf ^ 1);
         if (!(H2B_ABL & 8)) stage_load(t + 2 < ntiles ? t + 2 : t);
         if (!(H2B_ABL & 65) || t == 0) {
-          if (first_kb) {
+          if (first_kb || (H2B_ABL & 32)) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) pdst[MTHREADS * r] = sum[r];
           } else {
