@@ -139,7 +139,9 @@ def attention_ref(qkv, heads):
                                      (64, 16, 16, 1), (64, 5, 9, 2), (16, 72, 72, 1), (32, 80, 80, 1),
                                      (12, 72, 72, 1), (12, 5, 7, 2), (24, 80, 80, 1), (24, 9, 5, 1), (48, 16, 16, 1), (48, 5, 9, 2),
                                      # L = 5120 = 20 x 256: four key tiles per wave, query-tile loads two tiles ahead (d <= 16)
-                                     (16, 64, 80, 1), (12, 64, 80, 1), (8, 64, 80, 1)])
+                                     (16, 64, 80, 1), (12, 64, 80, 1), (8, 64, 80, 1),
+                                     # L = 512, B = 8: the smallest shape the fp16-pair backward takes (two 256-key blocks, 256 workgroup-blocks)
+                                     (16, 16, 32, 8), (32, 16, 32, 8)])
 def test_flash_attention_backward(d, H, W, B):
     g = torch.Generator().manual_seed(d + H)
     Cc = 8 * d
