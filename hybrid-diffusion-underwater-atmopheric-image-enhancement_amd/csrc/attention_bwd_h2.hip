@@ -50,6 +50,9 @@ constexpr int THREADS = 256;           // of the preparation kernels
 #ifndef H2B_WANT
 #define H2B_WANT 1024
 #endif
+#ifndef H2B_DQX
+#define H2B_DQX 1           // dev: 0 = the per-wave dQ form at d 16 too (A/B)
+#endif
 // Waves of a main-kernel workgroup, 32 keys each.  EIGHT: one workgroup per CU instead of two of four waves -- every query tile is
 // staged once per 256 keys instead of once per 128, and the workgroup's dQ partial tile (summed over its waves in LDS) goes to the
 // slab once per 256 keys: half the L2 float adds (timing ablation on the four-wave build: the adds were 13 % of the launch).
@@ -81,7 +84,14 @@ struct Geo {
   static constexpr int DQS = TQ + 4;                  // row stride (floats) of a wave's dQ partial tile [D][DQS], aliased on its scratch
   static_assert(TQ * GROW == 2048, "staging geometry: 128 chunks per piece");
   static_assert(D * DQS * 4 <= SCRB, "dQ partial tile must fit in the wave's scratch");
-  static constexpr int LDS_BYTES = 2 * BUFB + MW * SCRB;      // dynamic (eight waves: 70 KB)
+  // dQ across the workgroup (d 16, eight waves): every wave's dS images of BOTH subtiles stay in LDS until the tile's barrier, then wave w
+  // contracts ONE 16-query output tile (w & 3) over the 128 keys of four waves (half w >> 2) -- two partial tiles to sum instead of
+  // eight (timing ablations: the eight-way sum was ~40 of a tile's ~340 instructions per thread).  d 32 has no registers for
+  // four waves' K^T operands and keeps the per-wave form.
+  static constexpr bool DQX = (D == 16) && (MW == 8) && (H2B_DQX != 0);
+  static constexpr int IMG_BYTES = MW * (DQX ? NSUB : 1) * SCRB;
+  static constexpr int PART_BYTES = D * DQS * 4;                    // one partial tile [D][DQS] (DQX: two of them behind the images)
+  static constexpr int LDS_BYTES = 2 * BUFB + IMG_BYTES + (DQX ? 2 * PART_BYTES : 0);      // dynamic (d 16: 119 KB, d 32: 70 KB)
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -316,6 +326,7 @@ template <int D>
 __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a) {
   using G = Geo<D>;
   constexpr int TQ = G::TQ, NSUB = G::NSUB, MT = G::MT, RROW = G::RROW, GROW = G::GROW, CPR = G::CPR, RPART = G::RPART, BUFB = G::BUFB, DQS = G::DQS;
+  constexpr bool DQX = G::DQX;
   constexpr int QA_OFF = G::QA_OFF, QE_OFF = G::QE_OFF, OA_OFF = G::OA_OFF, OH_OFF = G::OH_OFF, SL_OFF = G::SL_OFF, SD_OFF = G::SD_OFF, SC_OFF = G::SC_OFF;
   // d-contracted products (S, dP'), four terms x0 y0, (x1 2^8)(y0 2^-8), (x0 2^-8)(y1 2^8), x1 y1:
   //   d 16: two terms share an MFMA's 32 slots -- row operand A0 = (x0 | x1 2^8) as staged, A1 = A0 2^-8; stationary B0 = (y0 | y0 2^-8),
@@ -401,8 +412,9 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
   // transposed reads of the same tiles (A operands of the products that sum over queries): lane 4q + p of a 16-lane group
   // addresses row 4g + q (then 16 + 4g + q), columns d = 16 mt + 4p .. + 3
   const int a3addr = (4 * g + (i16 >> 2)) * RROW + 8 * (i16 & 3);
-  unsigned char* scr = smem + 2 * BUFB + wave * SCRB;
-  float* sdq = reinterpret_cast<float*>(scr);
+  unsigned char* scr = smem + 2 * BUFB + wave * (DQX ? NSUB : 1) * SCRB;      // this wave's dS image(s): [subtile (DQX)][piece][key 0..31][SROW]
+  float* sdq = reinterpret_cast<float*>(scr);                                  // (per-wave form) the wave's partial tile, aliased on its image
+  unsigned char* const xpart = smem + 2 * BUFB + G::IMG_BYTES;                 // (DQX) partial tiles [key half][D][DQS]
   // the dS image of this wave: [piece][key 0..31][SROW bytes of 32 queries]
   const int swaddr = i16 * SROW + 8 * g;                              // + piece * SPART + kt * 16 * SROW + jq * 32
   const int sraddr = (8 * g + (i16 >> 2)) * SROW + 8 * (i16 & 3);     // + piece * SPART + jq * 32 (+ 4 * SROW: second half)
@@ -436,7 +448,16 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int p = 0; p < 2; ++p)
-        kT[mt][p] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_KT + p) * piece_n + (size_t)(16 * mt + i16) * L + key0 + 8 * g);
+        if (!DQX) kT[mt][p] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_KT + p) * piece_n + (size_t)(16 * mt + i16) * L + key0 + 8 * g);
+    // (DQX) k^T of the four waves of this wave's key half: [source wave][piece], rows d = i16, 32 keys along the contraction
+    u32x4 kT4[DQX ? 4 : 1][2];
+    if (DQX) {
+#pragma unroll
+      for (int sw = 0; sw < 4; ++sw)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          kT4[sw][p] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_KT + p) * piece_n + (size_t)i16 * L + kb * KB + (4 * (wave >> 2) + sw) * 32 + 8 * g);
+    }
     f32x4 dKa[2][MT], dVa[2][MT];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -548,7 +569,7 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
             if (!(H2B_ABL & 4)) {
 #pragma unroll
               for (int pc = 0; pc < 2; ++pc)
-                *reinterpret_cast<u32x2*>(scr + pc * SPART + kt * 16 * SROW + jq * 32 + swaddr) = u32x2{Sp[pc][2 * jq], Sp[pc][2 * jq + 1]};
+                *reinterpret_cast<u32x2*>(scr + (DQX ? sub * SCRB : 0) + pc * SPART + kt * 16 * SROW + jq * 32 + swaddr) = u32x2{Sp[pc][2 * jq], Sp[pc][2 * jq + 1]};
             }
           }
 #pragma unroll
@@ -567,10 +588,10 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
           }
         }
 
-        // ---- dQ^T of the subtile over this wave's 32 keys: the dS image read back transposed, keys along the contraction
+        // ---- (per-wave form) dQ^T of the subtile over this wave's 32 keys: the dS image read back transposed, keys along the contraction
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int jq = 0; jq < 2; ++jq) {
+        for (int jq = 0; jq < (DQX ? 0 : 2); ++jq) {
           u32x4 sT[2];
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
@@ -591,7 +612,54 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
         asm volatile("" ::: "memory");      // the next subtile's image stores stay behind these reads (same wave: in order)
       }
 
-      // the wave's partial tile [d][query] over its own scratch (its reads above are done: same wave, in order)
+      if (DQX) {
+        // ---- dQ^T across the workgroup: every wave's images of this tile are complete behind the barrier
+        lds_barrier();
+        const int nt = wave & 3, kh = wave >> 2;      // output tile = queries 16 nt .. + 15 (subtile nt >> 1, 16-query group nt & 1); keys of waves 4 kh .. 4 kh + 3
+        f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f}, accb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) {
+          const unsigned char* img = smem + 2 * BUFB + ((4 * kh + sw) * NSUB + (nt >> 1)) * SCRB + (nt & 1) * 32 + sraddr;
+          u32x4 sT[2];
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const u32x2 lo = lds_read_tr16(img + p * SPART), hi2 = lds_read_tr16(img + p * SPART + 4 * SROW);
+            sT[p] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
+          }
+          acca = mfma_f16(kT4[sw][0], sT[0], acca);        // k0 s0
+          accb = mfma_f16(kT4[sw][1], sT[0], accb);        // (k1 2^8) s0
+          accb = mfma_f16(kT4[sw][0], sT[1], accb);        // k0 (s1 2^8)
+        }
+        if (!(H2B_ABL & 2)) {
+          float* pw = reinterpret_cast<float*>(xpart + kh * G::PART_BYTES);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pw[(4 * g + r) * DQS + 16 * nt + i16] = __builtin_fmaf(accb[r], dnb, acca[r]);
+        } else if (acca[0] + accb[1] == 12345.f) *pdst = 1.f;
+        // tile t + 1 into the other buffer BEFORE the barrier: the next tile starts without another one
+        stage_store(buf ^ 1);
+        lds_barrier();
+        constexpr int NR = 1024 / MTHREADS;
+        float sum[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int e = tid + MTHREADS * r;
+          const float* s0 = reinterpret_cast<const float*>(xpart) + (e / TQ) * DQS + (e % TQ);
+          const float v = s0[0] + s0[G::PART_BYTES / 4];
+          sum[r] = __builtin_ldexpf(v * a.inv_sqrt_d, -(P_UP - DS_DOWN<D> + so + sv + bal)) * *reinterpret_cast<const float*>(tb + SC_OFF + (e % TQ) * 4);
+        }
+        if (!(H2B_ABL & 8)) stage_load(t + 2 < ntiles ? t + 2 : t);
+        if (!(H2B_ABL & 67) || t == 0) {
+          if (first_kb || (H2B_ABL & 32)) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) pdst[MTHREADS * r] = sum[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) unsafeAtomicAdd(pdst + MTHREADS * r, sum[r]);
+          }
+        }
+        continue;      // no closing barrier: the next tile's first LDS write that anyone else reads is behind ITS barrier
+      }
+      // (per-wave form) the wave's partial tile [d][query] over its own scratch (its reads above are done: same wave, in order)
       if (H2B_ABL & 2) {
         if (dQt[0][0][0][0] + dQt[0][1][0][1] == 12345.f) *pdst = 1.f;
         stage_store(buf ^ 1);
