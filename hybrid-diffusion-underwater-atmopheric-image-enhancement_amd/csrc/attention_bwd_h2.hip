@@ -51,7 +51,7 @@ constexpr int THREADS = 256;           // of the preparation kernels
 #define H2B_WANT 1024
 #endif
 #ifndef H2B_DQX
-#define H2B_DQX 1           // dev: 0 = the per-wave dQ form at d 16 too (A/B)
+#define H2B_DQX 3           // dev: bit 0 = dQ across the workgroup at d 16, bit 1 = at d 32 (A/B)
 #endif
 // Waves of a main-kernel workgroup, 32 keys each.  EIGHT: one workgroup per CU instead of two of four waves -- every query tile is
 // staged once per 256 keys instead of once per 128, and the workgroup's dQ partial tile (summed over its waves in LDS) goes to the
@@ -84,11 +84,11 @@ struct Geo {
   static constexpr int DQS = TQ + 4;                  // row stride (floats) of a wave's dQ partial tile [D][DQS], aliased on its scratch
   static_assert(TQ * GROW == 2048, "staging geometry: 128 chunks per piece");
   static_assert(D * DQS * 4 <= SCRB, "dQ partial tile must fit in the wave's scratch");
-  // dQ across the workgroup (d 16, eight waves): every wave's dS images of BOTH subtiles stay in LDS until the tile's barrier, then wave w
-  // contracts ONE 16-query output tile (w & 3) over the 128 keys of four waves (half w >> 2) -- two partial tiles to sum instead of
-  // eight (timing ablations: the eight-way sum was ~40 of a tile's ~340 instructions per thread).  d 32 has no registers for
-  // four waves' K^T operands and keeps the per-wave form.
-  static constexpr bool DQX = (D == 16) && (MW == 8) && (H2B_DQX != 0);
+  // dQ across the workgroup (eight waves): every wave's dS images of the tile stay in LDS until the tile's barrier, then wave w contracts
+  // ONE 16 x 16 output tile (w & 3: d 16 -- 16-query group of the 64; d 32 -- (row half, 16-query group)) over the 128 keys of four waves
+  // (half w >> 2) -- two partial tiles to sum instead of eight (timing ablations: the eight-way sum was ~40 of a tile's ~340 instructions
+  // per thread).  d 16: -6 %; d 32: -2.6 % (the four waves' K^T operands cost it six spilled registers outside the tile loop).
+  static constexpr bool DQX = (MW == 8) && (D == 16 ? (H2B_DQX & 1) != 0 : (H2B_DQX & 2) != 0);
   static constexpr int IMG_BYTES = MW * (DQX ? NSUB : 1) * SCRB;
   static constexpr int PART_BYTES = D * DQS * 4;                    // one partial tile [D][DQS] (DQX: two of them behind the images)
   static constexpr int LDS_BYTES = 2 * BUFB + IMG_BYTES + (DQX ? 2 * PART_BYTES : 0);      // dynamic (d 16: 119 KB, d 32: 70 KB)
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
       for (int sw = 0; sw < 4; ++sw)
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-          kT4[sw][p] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_KT + p) * piece_n + (size_t)i16 * L + kb * KB + (4 * (wave >> 2) + sw) * 32 + 8 * g);
+          kT4[sw][p] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_KT + p) * piece_n + (size_t)((D == 16 ? 0 : 16 * ((wave & 3) >> 1)) + i16) * L + kb * KB + (4 * (wave >> 2) + sw) * 32 + 8 * g);
     }
     f32x4 dKa[2][MT], dVa[2][MT];
 #pragma unroll
@@ -615,11 +615,14 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
       if (DQX) {
         // ---- dQ^T across the workgroup: every wave's images of this tile are complete behind the barrier
         lds_barrier();
-        const int nt = wave & 3, kh = wave >> 2;      // output tile = queries 16 nt .. + 15 (subtile nt >> 1, 16-query group nt & 1); keys of waves 4 kh .. 4 kh + 3
+        // output tile nt of four: d 16 -- queries 16 nt .. + 15 (subtile nt >> 1, 16-query group nt & 1); d 32 -- 16-query group nt & 1, rows d = 16 (nt >> 1) ..;
+        // keys of waves 4 kh .. 4 kh + 3
+        const int nt = wave & 3, kh = wave >> 2;
+        const int osub = (D == 16) ? (nt >> 1) : 0, ojq = nt & 1, omt = (D == 16) ? 0 : (nt >> 1);
         f32x4 acca = f32x4{0.f, 0.f, 0.f, 0.f}, accb = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sw = 0; sw < 4; ++sw) {
-          const unsigned char* img = smem + 2 * BUFB + ((4 * kh + sw) * NSUB + (nt >> 1)) * SCRB + (nt & 1) * 32 + sraddr;
+          const unsigned char* img = smem + 2 * BUFB + ((4 * kh + sw) * NSUB + osub) * SCRB + ojq * 32 + sraddr;
           u32x4 sT[2];
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
         if (!(H2B_ABL & 2)) {
           float* pw = reinterpret_cast<float*>(xpart + kh * G::PART_BYTES);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pw[(4 * g + r) * DQS + 16 * nt + i16] = __builtin_fmaf(accb[r], dnb, acca[r]);
+          for (int r = 0; r < 4; ++r) pw[(16 * omt + 4 * g + r) * DQS + 32 * osub + 16 * ojq + i16] = __builtin_fmaf(accb[r], dnb, acca[r]);
         } else if (acca[0] + accb[1] == 12345.f) *pdst = 1.f;
         // tile t + 1 into the other buffer BEFORE the barrier: the next tile starts without another one
         stage_store(buf ^ 1);
