@@ -26,7 +26,10 @@
 //   dK'^T += (Q 2^sq c_q)^T dS'  q0 s0 + (q0 2^-8)(s1 2^8) + q1 s0: a copy of the Q rows that gives the per-query factor c_q = 2^-t_q
 //                                back, form (ii); q0 2^-8 by v_pk_mul_f16 after the transposed read
 //   dQ'^T += k^T dS'^T           a: k0 s0, b: (k1 2^8) s0 + k0 (s1 2^8); a + b 2^-8 and the factor c_q when the tile leaves
-// Per 16x16 (query, key) tile at d 16: 8.5 MFMAs and ~30 vector instructions per lane (round 4: 12.5 / ~36; round 3: 15 / ~52).
+//                                contracted ACROSS the eight-wave workgroup: every wave's dS images stay in LDS until the tile's barrier, then each wave
+//                                takes one 16 x 16 output tile over the 128 keys of four waves -- two partial tiles to sum instead of eight (Geo::DQX)
+// Per 16x16 (query, key) tile at d 16: 8.5 MFMAs and ~33 vector instructions per lane in the ISA (exp2 4, P split 6, dS product + split 16,
+// operand shifts 3, the rest addressing and the dQ output path; round 4: 12.5 / ~36; round 3: 15 / ~52).
 // Error class (tests/test_gpu_backward.py, profiles/r05_attention_bwd_error_ratio.txt): rms against float64 <= the fp32-input
 // kernel's on every input family tried; the worst ELEMENT up to 2.3x (3x for one (sample, head) pair) -- where one score dominates
 // a row the pair's 2^-22 operand rounding is the whole error.

@@ -126,7 +126,7 @@ int contraction_mode();   // HDIFF_CONTRACT_*
 //   bit 3 (8)   the d_head 16 attention forward: the low five bits of every second piece of P masked (the P V product)
 //   bit 4 (16)  the attention backward (attention_bwd_h2.hip): the cross product o0 v1 of dP = dO V^T dropped
 //   bit 5 (32)  the attention backward: the product o1 p0 of dV^T = dO^T P dropped
-//   bit 6 (64)  the attention backward: the 2^-16 terms q0 s2 of dK^T and k0 s2 of dQ^T (third bf16 piece of dS) dropped
+//   bit 6 (64)  the attention backward: the low five bits of the second fp16 piece of dS masked (2^-17 of dS: dK^T and dQ^T)
 // `make mutant` builds bits 0, 1, 2, 4, 5 into build/libhdiff_mutant.so, `make mutant2` bits 3 and 6 into build/libhdiff_mutant2.so (bits 2
 // and 3 both end in the d_head 16 forward's output, bits 4 and 6 both in dK / dQ: one library could not tell which of them a red test
 // has seen).  The float64 error-class tests must FAIL on them.
