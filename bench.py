@@ -421,11 +421,20 @@ def other_configs(dev, small=False):
 # ----------------------------------------------------------------------------------------------------------------------
 # roofline.traffic: counter values measured by tools/profile_round.sh, valid only for the kernel sources they were taken on
 # ----------------------------------------------------------------------------------------------------------------------
+def _code_only(text):
+    """C++ source without comments and without whitespace: what the stamp of a traffic entry hashes, so that an edit of a comment
+    does not make a measurement look stale (string literals of these files hold no comment markers)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", "", text)
+
+
 def source_hash(names):
     h = hashlib.sha256()
     for n in names:
-        with open(os.path.join(CSRC, n), "rb") as f:
-            h.update(n.encode() + b"\0" + f.read())
+        with open(os.path.join(CSRC, n), "r", encoding="utf-8", errors="replace") as f:
+            h.update(n.encode() + b"\0" + _code_only(f.read()).encode())
     return h.hexdigest()[:16]
 
 

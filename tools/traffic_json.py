@@ -1,7 +1,7 @@
 """Dev tool: (re)generate profiles/roofline_traffic.json -- the table bench.py reads for `roofline.traffic` -- from the
 FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh, and STAMP it: the commit it was measured at, the time, and a
-hash of the kernel sources each entry belongs to.  bench.py recomputes those hashes and drops an entry whose kernel has
-changed since (a stale counter is not a measurement of the run that prints it).
+hash of the kernel sources each entry belongs to (code only: comments and whitespace are stripped, bench.source_hash).  bench.py
+recomputes those hashes and drops an entry whose kernel has changed since (a stale counter is not a measurement of the run that prints it).
 
   python3 tools/traffic_json.py <prof dir of profile_round.sh> <commit> [--out profiles/roofline_traffic.json]
   python3 tools/traffic_json.py --restamp <commit>      re-hash the sources for the EXISTING values (only when the
@@ -30,7 +30,7 @@ ALGORITHMIC = {
     "conv3x3_128_256_B16_pairs": 1074331648,
     "mha_flash_fwd_L65536_B16": 2147483648, "conv3x3_128_256_B16": 1074331648, "gn_stats_128_256_B16": 536870912,
     "mha_flash_bwd_L65536_B4": 4 * 65536 * 128 * 4 * 8,      # q, k, v, o, dO read; dq, dk, dv written: 8 tensors of B*C*L floats
-    "mha_flash_bwd_L65536_B4_bf16x3": 4 * 65536 * 128 * (3 * 6 + 2 * 4 + 3 * 4),   # main kernel (round 4): q, k, k^T as bf16 triples, v, dO as fp16 pairs read, dq / dk / dv written
+    "mha_flash_bwd_L65536_B4_bf16x3": 4 * 65536 * 128 * (4 + 4 + 8 + 4 + 4 + 4 + 4 + 3 * 4),   # main kernel (round 5), 2-byte pieces read: q (2), Q c_q (2), k (4), k^T (2), V' (2), dO per query (2), dO per head (2); dq / dk / dv written
 }
 
 
