@@ -385,8 +385,8 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
 
 def test_roofline_traffic_table_is_stamped_and_goes_stale_with_the_kernel_sources(tmp_path, monkeypatch):
     """profiles/roofline_traffic.json carries the commit it was measured at and a hash of each entry's kernel sources;
-    bench.load_traffic() reports an entry only while the sources still hash to that (a stale counter is not a measurement
-    of the run that prints it)."""
+    bench.load_traffic() reports an entry only while the sources' CODE (comments and whitespace stripped) still hashes to that (a
+    stale counter is not a measurement of the run that prints it)."""
     import bench
     table, stamp = bench.load_traffic()
     assert stamp.get("measured_at_commit") and stamp.get("measured_utc")
@@ -397,9 +397,15 @@ def test_roofline_traffic_table_is_stamped_and_goes_stale_with_the_kernel_source
     import shutil
     fake = tmp_path / "csrc"
     shutil.copytree(bench.CSRC, fake, ignore=shutil.ignore_patterns("build"))
+    # (the stamp hashes CODE: a comment or a blank line leaves an entry fresh ...)
     with open(fake / "attention.hip", "a") as fh:
-        fh.write("// edited\n")
+        fh.write("// edited\n\n/* a block\n   comment */\n")
     monkeypatch.setattr(bench, "CSRC", str(fake))
+    table_c, stamp_c = bench.load_traffic()
+    assert stamp_c["kernels"]["mha_flash_fwd_L65536_B16"] == stamp["kernels"]["mha_flash_fwd_L65536_B16"]
+    # (... a changed token does not)
+    with open(fake / "attention.hip", "a") as fh:
+        fh.write("static int edited_marker = 1;\n")
     table2, stamp2 = bench.load_traffic()
     assert "mha_flash_fwd_L65536_B16" not in table2 and stamp2["kernels"]["mha_flash_fwd_L65536_B16"].startswith("STALE")
     if stamp["kernels"]["gn_stats_128_256_B16"] == "fresh":
