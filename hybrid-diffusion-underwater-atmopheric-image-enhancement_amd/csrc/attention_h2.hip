@@ -331,6 +331,21 @@ __global__ __launch_bounds__(THREADS) void v_split_h2_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef H2_DMA
+#define H2_DMA 1             // K tiles global -> LDS by LDS-DMA (0: through registers like V; dev A/B)
+#endif
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+// One 1 KiB run global -> LDS without staging registers: lane i's 16 bytes at src + voff land at lds_dst + 16 i (global_load_lds_dwordx4).
+// M0 is written in the statement that uses it and restored (cdna_hip_programming.md, 'What hipcc does not do').  The compiler does not
+// count this load: the kernel waits with its own s_waitcnt vmcnt(0) in front of the barrier that publishes the tile.
+__device__ __forceinline__ void dma_1k(const unsigned char* src, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(src), "s"(lds_dst)
+               : "memory");
+}
+
 template <int D, int NQ>
 __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf16* __restrict__ ws, float* __restrict__ out,
                                                                       float* __restrict__ lse2, int C, int L, float one) {
@@ -389,8 +404,13 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
   const int vaddr = i16 * VROWB + 8 * g;
 
   // staging: chunk c = i * 256 + tid of the tile's 16-byte chunks (four K pieces, then two V pieces), copied as they are
-  constexpr int NKC = NKP * KT * D / 8, NVC = 2 * D * 8, NCH = NKC + NVC, NLD = (NCH + THREADS - 1) / THREADS;
+  // (H2_DMA) the four K pieces of a tile are eight contiguous 1 KiB runs in the workspace AND in LDS ([piece][key][32 bytes], no padding):
+  // each wave copies two of them by LDS-DMA -- no staging registers, no ds_write, no per-thread addresses; only V (padded rows) goes
+  // through registers
+  constexpr bool DMA = (H2_DMA != 0);
+  constexpr int NKC = DMA ? 0 : NKP * KT * D / 8, NVC = 2 * D * 8, NCH = NKC + NVC, NLD = (NCH + THREADS - 1) / THREADS;
   static_assert(NLD * THREADS - NCH <= NVC, "staging geometry");
+  static_assert(!DMA || (KPART == 2048 && THREADS == 256), "LDS-DMA geometry: eight 1 KiB runs, two per wave");
   const unsigned char* gsrc[NLD];
   int lds_off[NLD], gstep[NLD];
   u32x4 stage[NLD];
@@ -416,6 +436,17 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
       }
     }
   }
+  const unsigned lds0 = (unsigned)(size_t)(lds_byte*)&smem[0][0];
+  const unsigned char* kdma = reinterpret_cast<const unsigned char*>(wsq + 2 * piece_n);      // + piece * piece_n * 2 + tile * 2048 + half * 1024
+  // wave w copies runs 2 w, 2 w + 1 of the tile: piece w, its two 32-key halves
+  auto dma_k = [&](int t, int buf) {
+    if (!DMA) return;
+    const int ws_ = __builtin_amdgcn_readfirstlane(wave);      // the asm operands must be scalar registers
+    const unsigned char* src = kdma + (size_t)ws_ * (piece_n * 2) + (size_t)t * KPART;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * BUFB + ws_ * KPART);
+    dma_1k(src, lane * 16, dst);
+    dma_1k(src + 1024, lane * 16, dst + 1024);
+  };
   auto stage_load = [&](int t) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -610,8 +641,10 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
     if constexpr (!FIRST) if (!(H2_ABL & 16)) load_v(buf);
     stage_fn(std::integral_constant<int, 1>{}, first_tag, std::true_type{});
     if (!(H2_ABL & 4)) stage_store(buf ^ 1);                 // tile t + 1: its buffer was last read before the previous tile's barrier
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's K runs of tile t + 1 have landed in buffer buf ^ 1
     if (!(H2_ABL & 1)) __syncthreads();
     if (!(H2_ABL & 4)) stage_load((t + 2 < ntiles) ? t + 2 : ntiles - 1);
+    if (!(H2_ABL & 4)) dma_k((t + 2 < ntiles) ? t + 2 : ntiles - 1, buf);      // buffer buf is free: K(t) sits in kop since the last tile, V(t) was read above
     stage_fn(std::integral_constant<int, 2>{}, first_tag, std::true_type{}, buf ^ 1);    // K(t + 1) follows K(t) through kop
     stage_fn(std::integral_constant<int, 3>{}, first_tag, std::true_type{});
   };
@@ -620,9 +653,12 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
   const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   stage_load(0);
+  dma_k(0, 0);
   stage_store(0);
+  if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   stage_load(ntiles > 1 ? 1 : 0);
+  dma_k(ntiles > 1 ? 1 : 0, 1);
   load_k(0);
 #pragma unroll
   for (int n = 0; n < 4 * NQK; ++n) qk_mfma(0, 0, n);

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Dev tool: produce the per-round profile artefacts on the GPU box (run through gpurun from the repo root):
 #   bash tools/profile_round.sh <tag> <commit> [part]   -> gpurun_out/prof_<tag>/...   (copy what is to be judged into profiles/)
-# part = traces | pmc1 | pmc2 (one gpurun call each: a call is limited to 20 minutes) | pmcbwd | traintraces (subsets, after a change to the
-# attention backward alone) | summary (no GPU: run it where the merged
+# part = traces | pmc1 | pmc2 (one gpurun call each: a call is limited to 20 minutes) | pmcbwd | traintraces | pmcfwd (subsets, after a change to one
+# attention kernel alone) | summary (no GPU: run it where the merged
 # gpurun_out/ is, i.e. in the build container) | all
 # <commit> = `git rev-parse --short HEAD` of the tree that was sent (the box has no .git): it is stamped, with hashes of the
 # kernel sources, into gpurun_out/prof_<tag>/roofline_traffic.json, the table bench.py reads for `roofline.traffic`.
@@ -66,6 +66,12 @@ run_pmc bwd_sq2 $SQ2 -- python3 tools/attn_bwd_once.py 4
 run_pmc bwd32_sq1 $SQ1 -- python3 tools/attn_bwd_once.py 4 256 16384
 run_pmc bwd32_sq2 $SQ2 -- python3 tools/attn_bwd_once.py 4 256 16384
 for c in FETCH_SIZE WRITE_SIZE; do run_pmc bwd_$c $c -- python3 tools/attn_bwd_once.py 4; done
+fi
+if [ "$PART" = pmcfwd ]; then   # only the d_head 16 forward's passes and the headline trace (after a change to attention_h2.hip alone)
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/bench -o bench -- python3 bench.py --steps 3 --warmup 1 --no-alt --no-extras --no-cpu-baseline > $P/bench_line.json 2> $P/bench.err
+run_pmc x3_sq1 $SQ1 -- python3 tools/attn_once.py 16
+run_pmc x3_sq2 $SQ2 -- python3 tools/attn_once.py 16
+for c in FETCH_SIZE WRITE_SIZE; do run_pmc x3_$c $c -- python3 tools/attn_once.py 16; done
 fi
 if [ "$PART" = traintraces ]; then   # only the two training traces of `traces`
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/train -o train -- python3 tools/bench_train.py --size 256 --batch 4 --steps 1 --warmup 1 > $P/train_line.json 2> $P/train.err
