@@ -53,6 +53,9 @@ constexpr int THREADS = 256;           // of the preparation kernels
 #ifndef H2B_WANT
 #define H2B_WANT 1024
 #endif
+#ifndef H2B_DMA
+#define H2B_DMA 1           // dev: the tile's piece rows global -> LDS by LDS-DMA (eight-wave form; 0: through registers; A/B)
+#endif
 #ifndef H2B_DQX
 #define H2B_DQX 3           // dev: bit 0 = dQ across the workgroup at d 16, bit 1 = at d 32 (A/B)
 #endif
@@ -119,6 +122,17 @@ __device__ __forceinline__ void lds_barrier() {
   else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+// One 1 KiB run global -> LDS without staging registers (global_load_lds_dwordx4: lane i's 16 bytes at src + voff land at lds_dst + 16 i).
+// M0 is written in the statement that uses it and restored; the compiler does not count this load: the kernel waits with its own
+// s_waitcnt vmcnt(0) in front of the barrier that publishes the tile (attention_h2.hip does the same for its K tiles).
+__device__ __forceinline__ void dma_1k(const unsigned char* src, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(src), "s"(lds_dst)
+               : "memory");
+}
 __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -374,7 +388,11 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
   // ---- staging of one query tile: 1024 chunks of 16 bytes (two row pieces each of Q, of q c_q, of dO per query and of dO per head), two per thread;
   // 14 - lse2, -delta' and c_q of the tile's queries by the first TQ threads
   // the 1024 chunks: blocks {Q, q c_q, dO per query, dO per head} x 2 pieces x 128 chunks; thread tid takes chunk tid + MTHREADS i
-  constexpr int NST = 1024 / MTHREADS;
+  // (BDMA) the eight 2 KiB piece regions of a tile are contiguous in the workspace and in LDS (no row padding): wave w copies region w as two
+  // 1 KiB LDS-DMA runs; only the three per-query vectors go through registers
+  constexpr bool BDMA = DQX && (H2B_DMA != 0);
+  static_assert(!BDMA || (RROW == GROW && RPART == 2048 && MW == 8), "LDS-DMA geometry");
+  constexpr int NST = BDMA ? 0 : 1024 / MTHREADS;
   static_assert(MTHREADS == 256 || MTHREADS == 512, "staging geometry");
   static_assert(S_O - S_Q == S_OH - S_QE && G::OA_OFF - G::QA_OFF == G::OH_OFF - G::QE_OFF, "chunk i + 1 of a thread = chunk i moved by a fixed amount");
   unsigned goff0;
@@ -390,8 +408,18 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
   auto gslot = [&](int i) -> size_t { return (size_t)(MTHREADS == 512 ? i * (S_O - S_Q) : (i == 0 ? 0 : i == 1 ? S_QE - S_Q : i == 2 ? S_O - S_Q : S_OH - S_Q)) * (piece_n * 2); };
   auto lslot = [&](int i) { return MTHREADS == 512 ? i * (OA_OFF - QA_OFF) : (i == 0 ? 0 : i == 1 ? QE_OFF : i == 2 ? OA_OFF : OH_OFF); };
   const unsigned char* wsb = reinterpret_cast<const unsigned char*>(wsh);
-  u32x4 stage[NST];
+  u32x4 stage[NST ? NST : 1];
   float stage_l = 0.f, stage_d = 0.f, stage_c = 1.f;
+  const unsigned lds0 = (unsigned)(size_t)(lds_byte*)smem;
+  auto dma_tile = [&](int t, int buf) {
+    if (!BDMA) return;
+    const int w_ = __builtin_amdgcn_readfirstlane(wave);                 // region w: slots S_Q, S_Q + 1, S_QE, S_QE + 1, S_O, S_O + 1, S_OH, S_OH + 1
+    const int slot = (w_ < 4) ? w_ : w_ + (S_O - 4);
+    const unsigned char* src = wsb + (size_t)slot * (piece_n * 2) + (size_t)t * (TQ * GROW);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * BUFB + w_ * RPART);
+    dma_1k(src, lane * 16, dst);
+    dma_1k(src + 1024, lane * 16, dst + 1024);
+  };
   auto stage_load = [&](int t) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) stage[i] = *reinterpret_cast<const u32x4*>(wsb + gslot(i) + goff0 + (size_t)t * (TQ * GROW));
@@ -472,7 +500,9 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
 
     __syncthreads();              // the previous key block's last tile is fully consumed
     stage_load(0);
+    dma_tile(0, 0);
     stage_store(0);
+    if (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!(H2B_ABL & 8)) stage_load(1);
 
@@ -484,6 +514,8 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
     for (int t = 0; t < ntiles; ++t) {
       const int buf = t & 1;
       const unsigned char* tb = smem + buf * BUFB;
+      // (BDMA) the rows of tile t + 1 into the other buffer: its piece regions were last read before the previous tile's first barrier
+      if (!(H2B_ABL & 8)) dma_tile(t + 1 < ntiles ? t + 1 : t, buf ^ 1);
       float* pdst = part + (size_t)t * (D * TQ) + tid;
 
       f32x4 dQt[NSUB][2][MT];
@@ -643,6 +675,7 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2_kernel(const BwdH2Args a)
         } else if (acca[0] + accb[1] == 12345.f) *pdst = 1.f;
         // tile t + 1 into the other buffer BEFORE the barrier: the next tile starts without another one
         stage_store(buf ^ 1);
+        if (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's runs of tile t + 1 have landed
         lds_barrier();
         constexpr int NR = 1024 / MTHREADS;
         float sum[NR];
