@@ -517,9 +517,12 @@ int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* 
       const int total = B * heads * L;
       (void)hipGetLastError();
       hipLaunchKernelGGL(mha_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, o, d_o, delta, C, D, L, total);
-      launch_mha_bwd_h2(qkv, d_o, lse2, delta, dqkv, ws, B, C, heads, L, stream);
-      HDIFF_CHECK_LAUNCH("mha_bwd (split-bf16) kernels");
-      return HDIFF_OK;
+      if (launch_mha_bwd_h2(qkv, d_o, lse2, delta, dqkv, ws, B, C, heads, L, stream)) {
+        HDIFF_CHECK_LAUNCH("mha_bwd (split-bf16) kernels");
+        return HDIFF_OK;
+      }
+      // the device refused the split kernel's LDS size (nothing of it was launched): the fp32-input backward below takes the call -- its
+      // workspace need is never larger (hdiff_mha_flash_bwd_workspace reports the maximum of the two)
     }
   }
   const BwdGeom g = bwd_geometry(B, heads, L, D);

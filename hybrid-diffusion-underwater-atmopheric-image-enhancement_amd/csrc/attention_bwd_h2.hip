@@ -35,6 +35,7 @@
 // a row the pair's 2^-22 operand rounding is the whole error.
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -84,7 +85,7 @@ struct Geo {
                                                       // row and transposed reads alike, measured no faster: 16.39 vs 16.35 ms)
   static constexpr int CPR = GROW / 16;               // 16-byte chunks per row
   static constexpr int RPART = TQ * RROW;
-  // rows of (q0, q1 2^8); of q c_q likewise; of dO scaled per query (o0, o1 2^8); of dO scaled per head likewise
+  // rows of (q0, q1 2^8); of Q 2^sq c_q (x0, x1: form (ii), unshifted); of dO scaled per query (o0, o1: form (ii)); of dO scaled per head likewise
   static constexpr int QA_OFF = 0, QE_OFF = 2 * RPART, OA_OFF = 4 * RPART, OH_OFF = 6 * RPART;
   static constexpr int SL_OFF = 8 * RPART, SD_OFF = SL_OFF + TQ * 4, SC_OFF = SD_OFF + TQ * 4, BUFB = SC_OFF + TQ * 4;
   static constexpr int DQS = TQ + 4;                  // row stride (floats) of a wave's dQ partial tile [D][DQS], aliased on its scratch
@@ -202,7 +203,7 @@ __device__ __forceinline__ int balance_exp(unsigned qmax_bits, unsigned kmax_bit
 }
 
 // Piece slots of one (sample, head), each L * D fp16: rows of q (q0, q1 2^8); rows of Q 2^sq c_q (x0, x1); rows of k (k0, k0 2^-8,
-// k1 2^8, k1); k transposed [D][L] (k0, k1 2^8); rows of V' (v0, v0 2^-8, v1 2^8, v1); rows of dO scaled per query (o0, o1 2^8); rows of
+// k1 2^8, k1); k transposed [D][L] (k0, k1 2^8); rows of V' (v0, v1: form (ii), two slots used of the four reserved); rows of dO scaled per query (o0, o1: unshifted); rows of
 // dO scaled per head (x0, x1); the L factors c_q (fp32) in the last slot
 enum { S_Q = 0, S_QE = 2, S_K = 4, S_KT = 8, S_V = 10, S_O = 12, S_OH = 14, S_C = 16, S_COUNT = 17 };
 enum { M_V = 0, M_O = 1, M_Q = 2, M_K = 3, M_COUNT = 4 };      // maxima per (sample, head)
@@ -253,6 +254,7 @@ __device__ __forceinline__ void pair4(float xa, float xb, float up, unsigned& x0
 template <int D>
 __global__ __launch_bounds__(THREADS) void mha_bwd_split_h2_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                                    __bf16* __restrict__ ws, const unsigned* __restrict__ absmax,
+                                                                   const float* __restrict__ lse2, const float* __restrict__ delta,
                                                                    int C, int L, float qscale, float one) {
   const int heads = C / D;
   const int which = blockIdx.y / heads, head = blockIdx.y - which * heads, b = blockIdx.z;     // 0: Q, 1: K, 2: V, 3: dO
@@ -276,13 +278,24 @@ __global__ __launch_bounds__(THREADS) void mha_bwd_split_h2_kernel(const float* 
       for (int d = 0; d < D; ++d) rm = fmaxf(rm, fabsf(dsrc[(size_t)d * L]));
       tq = max_exp(mx[M_O]) - ((int)((__builtin_bit_cast(unsigned, rm) >> 23) & 0xffu) - 127);
       tq = tq < 0 ? 0 : (tq > 24 ? 24 : tq);
-      if (which == 3) reinterpret_cast<float*>(base + (size_t)S_C * piece)[l] = __builtin_ldexpf(1.0f, -tq);      // c_q
+      if (which == 3) {
+        float* cq = reinterpret_cast<float*>(base + (size_t)S_C * piece);
+        cq[l] = __builtin_ldexpf(1.0f, -tq);      // c_q
+        // (pipelined kernel) the two per-query starting values of the d-contracted chains, per 32-query tile [tile][2][32] behind the L factors:
+        // 14 - lse2 (S') and -delta'_q = -delta_q 2^so 2^sv 2^t_q (dP'), the powers of two one after the other (each a finite float)
+        const size_t bh = (size_t)b * heads + head;
+        float* nld = cq + L + (size_t)(l >> 5) * 64 + (l & 31);
+        nld[0] = (float)P_UP - lse2[bh * L + l];
+        nld[32] = ((-delta[bh * L + l] * __builtin_ldexpf(1.0f, scale_exp_o(mx[M_O]))) * __builtin_ldexpf(1.0f, scale_exp_v(mx[M_V]))) * __builtin_ldexpf(1.0f, tq);
+      }
     }
-    const float scq = which == 3 ? sc * __builtin_ldexpf(1.0f, tq) : sc;
+    // the two powers of two one after the other: 2^(so + t_q) itself can leave fp32 (a head whose dO is all zero or below 2^-91 has so = 113,
+    // a silent row t_q = 24: 0 x inf = NaN), each factor cannot, and after the first one every row's maximum is at most 2^14 2^-t_q
+    const float tqf = which == 3 ? __builtin_ldexpf(1.0f, tq) : 1.0f;
     unsigned h[4][D / 2];          // x0, x0 2^-8, x1 2^8, x1 as packed fp16 pairs (channels 2 j, 2 j + 1)
 #pragma unroll
     for (int j = 0; j < D / 2; ++j)
-      pair4(src[(size_t)(2 * j) * L + l] * scq, src[(size_t)(2 * j + 1) * L + l] * scq, up, h[0][j], h[1][j], h[2][j], h[3][j]);
+      pair4((src[(size_t)(2 * j) * L + l] * sc) * tqf, (src[(size_t)(2 * j + 1) * L + l] * sc) * tqf, up, h[0][j], h[1][j], h[2][j], h[3][j]);
     // q: (x0, x1 2^8); k: all four; V', dO' (maxima in [2^13, 2^14): form (ii)): (x0, x1)
     const int slot0 = which == 0 ? S_Q : which == 1 ? S_K : which == 2 ? S_V : S_O;
 #pragma unroll
@@ -783,6 +796,443 @@ __global__ void mha_dq_reduce_h2_kernel(const float* __restrict__ part, float* _
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the d_head 16 kernel as a SOFTWARE PIPELINE over 32-query tiles, ONE workgroup barrier per tile.
+// Why (profiles/r05_pmc_summary.txt): the kernel above runs at ~52 % of its own issue floor, MFMA / vector co-execution
+// 0.25 -- per 64-query tile all eight waves meet at two barriers, and between them sits a phase that is nothing but latency: the
+// transposed reads of the dS images, a chain of dependent dQ MFMAs, the partial tile through LDS, a second barrier, the cross-wave sum and
+// the slab adds, with the matrix AND the vector pipe idle on every SIMD at once (the dQ output path: 23 % of the launch).
+// Here the three pieces of a tile's work run in three consecutive iterations, each between the same two barriers as the MAIN phase of a
+// later tile, so their latencies hide under its instruction stream:
+//   iteration u:   main(u)   S', dP', P', dS', dV^T, dK^T of tile u from tile buffer u & 1; dS' images -> image set u & 1
+//                  dq(u - 1) dQ'^T of tile u - 1 contracted across the workgroup out of image set (u - 1) & 1 (complete since the last
+//                            barrier): wave w = (key quarter w >> 1, 16-query group w & 1), partial tile -> xpart[(u - 1) & 1]
+//                  sum(u - 2) the four key quarters of tile u - 2 summed out of xpart[u & 1], unscaled, to the slab (store / L2 float add)
+//                  LDS-DMA of tile u + 1 into tile buffer (u + 1) & 1 (last read before the previous barrier)
+//   barrier
+// Nothing per query is needed after the main phase: the two chain starts (14 - lse2, -delta') come per tile from the split pass and the factor
+// c_q = 2^-t_q is given back by the slab reduce kernel (a power of two: exact), so a tile buffer can be overwritten one iteration after its
+// main phase.  Same operand formats, same products, same summation order inside a tile as the kernel above; dQ's key-quarter partials
+// are summed in a fixed order: bitwise reproducible.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef H2B_PIPE
+#define H2B_PIPE 1            // dev: 0 = d_head 16 on the two-barrier kernel above (A/B)
+#endif
+#ifndef H2P_OPT
+#define H2P_OPT 3             // switches of the pipelined kernel (A/B builds with -DH2P_OPT=<bits>): 1 static priority for waves 4-7 (the second-dispatched
+#endif                        // half loses every issue arbitration to its SIMD partner otherwise: -1.3 %), 2 no trailing s_nop in the dS split statements
+                              // (the slot program puts an MFMA behind each: the partial-write hazard is covered; 0.0 %)
+#ifndef H2P_ABL
+#define H2P_ABL 0             // dev: timing ablations of the pipelined kernel (results wrong by construction): 1 no exp / split chain, 2 no dq stage,
+#endif                        // 4 no sum stage, 8 no main-phase MFMAs, 16 no dS image stores, 32 no barrier, 64 no tile copies, 128 no operand LDS reads
+struct GeoP {
+  static constexpr int D = 16, TQ = 32, RROW = 32, RPART = TQ * RROW;      // a tile's piece region: 32 rows of 32 bytes = one 1 KiB LDS-DMA run
+  static constexpr int QA_OFF = 0, QE_OFF = 2 * RPART, OA_OFF = 4 * RPART, OH_OFF = 6 * RPART, SL_OFF = 8 * RPART, SD_OFF = SL_OFF + TQ * 4;
+  static constexpr int BUFB = SD_OFF + TQ * 4;                              // 8448
+  static constexpr int IMGB = MW * SCRB;                                    // one image set: every wave's [piece][32 keys][SROW]
+  static constexpr int DQS = TQ + 4;                                        // row stride (floats) of a partial tile [16 d][DQS]: conflict-free b32 stores
+  static constexpr int PARTB = D * DQS * 4, XPB = 4 * PARTB;                // four key quarters
+  static constexpr int NBUF = 3;                                            // tile buffers: tile t lives in buffer t % 3 (copied two iterations ahead)
+  static constexpr int KTB = MW * 2 * 1024;                                 // k^T of every wave's 32 keys as MFMA A operands: [wave][piece][lane][16 bytes]
+  static constexpr int IMG_OFF = NBUF * BUFB, XP_OFF = IMG_OFF + 2 * IMGB, KT_OFF = XP_OFF + 2 * XPB, LDS_BYTES = KT_OFF + KTB;      // 133 888
+  static_assert(MW == 8 || !H2B_PIPE, "the pipelined kernel is written for eight waves");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+// 256 bytes global -> LDS: lane i's 4 bytes at src + 4 i land at lds_dst + 4 i (global_load_lds_dword; see dma_1k)
+__device__ __forceinline__ void dma_256(const unsigned char* src, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(src), "s"(lds_dst)
+               : "memory");
+}
+
+// the three stages of split2_scaled as separate statements (same instructions, same order per value): the pipelined kernel places them in
+// different issue slots between its MFMAs
+__device__ __forceinline__ void ds_split_a(float a0, float a1, float b0, float b1, float c, unsigned& ha0, unsigned& hb0) {
+  asm("v_fma_mixlo_f16 %0, %2, %6, 0\n\t"
+      "v_fma_mixlo_f16 %1, %4, %6, 0\n\t"
+      "v_fma_mixhi_f16 %0, %3, %6, 0\n\t"
+      "v_fma_mixhi_f16 %1, %5, %6, 0"
+#if !(H2P_OPT & 2)
+      "\n\ts_nop 0"
+#endif
+      : "=&v"(ha0), "=&v"(hb0)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(c));
+}
+__device__ __forceinline__ void ds_split_b(float a0, float a1, float b0, float b1, float c, unsigned ha0, unsigned hb0, float& r0, float& r1, float& r2,
+                                           float& r3) {
+  asm("v_fma_mix_f32 %0, %4, %8, -%9 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %2, %6, %8, -%10 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %1, %5, %8, -%9 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %3, %7, %8, -%10 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(c), "v"(ha0), "v"(hb0));
+}
+__device__ __forceinline__ void ds_split_c(float r0, float r1, float r2, float r3, float up, unsigned& ha1, unsigned& hb1) {
+  asm("v_fma_mixlo_f16 %0, %2, %6, 0\n\t"
+      "v_fma_mixlo_f16 %1, %4, %6, 0\n\t"
+      "v_fma_mixhi_f16 %0, %3, %6, 0\n\t"
+      "v_fma_mixhi_f16 %1, %5, %6, 0"
+#if !(H2P_OPT & 2)
+      "\n\ts_nop 0"
+#endif
+      : "=&v"(ha1), "=&v"(hb1)
+      : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(up));
+}
+
+__global__ __launch_bounds__(MTHREADS) void mha_bwd_h2p_kernel(const BwdH2Args a) {
+  constexpr int D = 16;
+  using G = GeoP;
+  constexpr int TQ = G::TQ, RROW = G::RROW, RPART = G::RPART, BUFB = G::BUFB, DQS = G::DQS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int C = a.C, L = a.L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const TileId tile = xcd_tile();
+  const int head = tile.head, b = tile.b, heads = gridDim.y, split = tile.x;
+  const size_t piece_n = (size_t)L * D;
+  const __bf16* wsh = a.ws + ((size_t)b * heads + head) * S_COUNT * piece_n;
+  const unsigned char* wsb = reinterpret_cast<const unsigned char*>(wsh);
+  const unsigned char* nld = wsb + (size_t)S_C * piece_n * 2 + (size_t)L * 4;      // [tile][2][32] floats: 14 - lse2, -delta'
+  float* part = a.dq_part + (size_t)split * a.split_stride + (size_t)b * a.batch_stride + (size_t)head * D * L;
+  float* kout = a.dqkv + ((size_t)b * 3 * C + (size_t)C + (size_t)head * D) * L;
+  float* vout = kout + (size_t)C * L;
+  const int ntiles = L / TQ;
+  const int nkb_total = L / KB;
+  const int kb_begin = split * a.kb_per_split;
+  const int kb_end = (kb_begin + a.kb_per_split < nkb_total) ? kb_begin + a.kb_per_split : nkb_total;
+  const unsigned* mx = a.absmax + ((size_t)b * heads + head) * M_COUNT;
+  const int so = scale_exp_o(mx[M_O]), sv = scale_exp_v(mx[M_V]), sq = scale_exp_q(mx[M_Q]), bal = balance_exp(mx[M_Q], mx[M_K], a.qscale);
+  const float one = a.one;
+  const float dnb = __builtin_ldexpf(1.0f, -PAIR_SHIFT);
+  const float dsdn = __builtin_ldexpf(one, -DS_DOWN<D>);
+  const float up8 = __builtin_ldexpf(one, PAIR_SHIFT);
+  const int dq_unscale = -(P_UP - DS_DOWN<D> + so + sv + bal);
+
+  const int doff = 8 * (g & 1);
+  const bool hi = g >> 1;
+  const unsigned lds0 = (unsigned)(size_t)(lds_byte*)smem;
+  // VMEM roles by wave half, so that no wave ever waits for a slab add (a no-return float add stays counted in vmcnt for ~3000 cycles with every
+  // CU issuing, vmcnt retires in order, and a tile lasts less than that): waves 0-3 copy the tile -- wave w the two piece regions 2 w, 2 w + 1
+  // (slots S_Q, S_QE, S_O, S_OH and their second pieces), wave 0 also the two start vectors -- and wait for their copies; waves 4-7 send the
+  // finished partial tile to the slab (two floats per thread) and never wait for memory
+  const int w_ = __builtin_amdgcn_readfirstlane(wave);
+  const bool copier = w_ < 4;
+  const unsigned char* dma_src = wsb + (size_t)(w_ == 0 ? S_Q : w_ == 1 ? S_QE : w_ == 2 ? S_O : S_OH) * (piece_n * 2);
+  auto dma_tile = [&](int t, int boff) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + boff + (w_ & 3) * 2 * RPART);
+    dma_1k(dma_src + (size_t)t * RPART, lane * 16, dst);
+    dma_1k(dma_src + piece_n * 2 + (size_t)t * RPART, lane * 16, dst + RPART);
+    if (w_ == 0) dma_256(nld + (size_t)t * 256, lane * 4, __builtin_amdgcn_readfirstlane(lds0 + boff + G::SL_OFF));
+  };
+
+  const int a1addr = (hi ? 1 : 0) * RPART + i16 * RROW + doff * 2;                  // row reads (Q, dO): the piece of this lane half, row i16
+  const int a3addr = (4 * g + (i16 >> 2)) * RROW + 8 * (i16 & 3);                   // transposed reads of the same tiles
+  const int swaddr = i16 * SROW + 8 * g;                                            // dS image stores: + piece * SPART + kt * 16 * SROW + jq * 32
+  const int sraddr = (8 * g + (i16 >> 2)) * SROW + 8 * (i16 & 3);                   // dS image transposed reads
+  // dq role of this wave: 16-query group, key quarter (source waves 2 kq, 2 kq + 1)
+  const int ojq = wave & 1, kq = wave >> 1;
+  auto down = [&](const u32x4& x) {
+    unsigned w4[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) asm("v_pk_mul_f16 %0, %1, %2" : "=v"(w4[w]) : "v"(x[w]), "v"(PAIR_DOWN2));
+    return u32x4{w4[0], w4[1], w4[2], w4[3]};
+  };
+#define SLOT() __builtin_amdgcn_sched_barrier(0)
+
+  if ((H2P_OPT & 1) && !copier) __builtin_amdgcn_s_setprio(1);
+  for (int kb = kb_begin; kb < kb_end; ++kb) {
+    const int key0 = kb * KB + wave * 32;
+    u32x4 kB[2][2], vB[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const size_t row = (size_t)(key0 + kt * 16 + i16) * D + doff;
+        kB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_K + 2 * j + (hi ? 1 : 0)) * piece_n + row);      // (k0 | k0 2^-8), (k1 2^8 | k1)
+        vB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_V + j) * piece_n + row);                          // (o0 | o1)(v_j | v_j)
+      }
+    // k^T of this wave's 32 keys (rows d = i16, keys along the contraction) in MFMA operand order into LDS: the dq stage reads the two waves
+    // of its key quarter from there every tile (lane-contiguous 16-byte reads) instead of holding 16 registers for the whole sweep
+    u32x4 kTown[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) kTown[p] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_KT + p) * piece_n + (size_t)i16 * L + key0 + 8 * g);
+    f32x4 dKa[2], dVa[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) { dKa[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dVa[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    __syncthreads();              // the previous key block's last iterations are done with every LDS region
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(smem + G::KT_OFF + (wave * 2 + p) * 1024 + lane * 16) = kTown[p];
+    if (copier) { dma_tile(0, 0); dma_tile(1, BUFB); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // the row operands and chain starts of a tile are read one iteration AHEAD (behind the last MFMA that uses the current ones), so that an
+    // iteration opens with matrix work instead of an LDS round trip that both waves of a SIMD sit out together (timing ablation: the operand
+    // reads were 18 % of the launch); tile u + 1 is therefore in LDS before the barrier that ends iteration u - 1: three tile buffers
+    u32x4 qA[2][2], oA[2];
+    f32x4 negl[2], negd[2];
+    auto rd_rows = [&](int jq, int boff) {
+      const unsigned char* tb = smem + boff;
+      if (H2P_ABL & 128) { qA[jq][0] = kB[0][0]; oA[jq] = vB[0][0]; negl[jq] = f32x4{0.f, 0.f, 0.f, 0.f}; negd[jq] = negl[jq]; return; }
+      qA[jq][0] = *reinterpret_cast<const u32x4*>(tb + G::QA_OFF + a1addr + jq * 16 * RROW);
+      oA[jq] = *reinterpret_cast<const u32x4*>(tb + G::OA_OFF + a1addr + jq * 16 * RROW);
+      negl[jq] = *reinterpret_cast<const f32x4*>(tb + G::SL_OFF + (16 * jq + 4 * g) * 4);
+      negd[jq] = *reinterpret_cast<const f32x4*>(tb + G::SD_OFF + (16 * jq + 4 * g) * 4);
+    };
+    rd_rows(0, 0); rd_rows(1, 0);
+    qA[0][1] = down(qA[0][0]); qA[1][1] = down(qA[1][0]);
+
+    // One iteration = issue slots in a fixed order, fenced (sched_barrier) so that the order written here is the order issued: about one
+    // MFMA and one group of ~4 vector instructions per slot (an MFMA holds the vector issue port for 8 of its 16 cycles; left to the scheduler
+    // the matrix products clump and the dq / sum stages sink to the end of the block as a serial tail).  Chains of dependent MFMAs are
+    // interleaved two and two.
+    auto iteration = [&](auto main_tag, auto dq_tag, auto sum_tag, auto dma_tag, auto pre_tag, auto first_tag, int u, int bcur, int bnext, int bnn) {
+      constexpr bool MAIN = decltype(main_tag)::value, DQ = decltype(dq_tag)::value && !(H2P_ABL & 2), SUM = decltype(sum_tag)::value && !(H2P_ABL & 4);
+      constexpr bool DMA = decltype(dma_tag)::value, PRE = decltype(pre_tag)::value, FIRST = decltype(first_tag)::value;
+      const int par = u & 1;
+      const unsigned char* tb = smem + bcur;
+      unsigned char* scr = smem + G::IMG_OFF + par * G::IMGB + wave * SCRB;
+      const unsigned char* img = smem + G::IMG_OFF + (par ^ 1) * G::IMGB + (2 * kq) * SCRB + ojq * 32 + sraddr;      // source wave 2 kq (+ SCRB: 2 kq + 1)
+      u32x4 qT[2], oT[2], qTd, sT[2][2], kT2[2][2];
+      f32x4 S[2][2], dP[2][2], acca, accb;
+      unsigned Pp[2][2][4], Sp[2][2][4];          // [key tile][piece][word]: the B operands of dV^T / dK^T over the tile's 32 queries
+      auto vec4 = [](const unsigned (&w)[4]) { return u32x4{w[0], w[1], w[2], w[3]}; };
+      float pe[2][2][4], ds[2][2][4], rr[2][2][4];
+      float sraw[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* xs0 = reinterpret_cast<const float*>(smem + G::XP_OFF + par * G::XPB) + (tid >> 5 & 7) * DQS + (tid & 31);
+      // ---- memory roles first: the copy of tile u + 1 / the partial tile of tile u - 2 out of xpart[par]
+      if (copier) {
+        if constexpr (MAIN && DMA && !(H2P_ABL & 64)) dma_tile(u + 2, bnn);
+      } else if constexpr (SUM) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sraw[q] = xs0[q * (G::PARTB / 4)];      // rows d = 0 .. 7; summed a few slots later: no wait here
+      }
+      SLOT();
+      auto rd_tr = [&](int p) {
+        if (H2P_ABL & 128) { qT[p] = kB[1][p]; oT[p] = vB[1][p]; return; }
+        const unsigned char* sqp = tb + G::QE_OFF + p * RPART + a3addr;
+        const u32x2 q0 = lds_read_tr16(sqp), q1 = lds_read_tr16(sqp + 16 * RROW);
+        qT[p] = u32x4{q0[0], q0[1], q1[0], q1[1]};
+        const unsigned char* sop = tb + G::OH_OFF + p * RPART + a3addr;
+        const u32x2 o0 = lds_read_tr16(sop), o1 = lds_read_tr16(sop + 16 * RROW);
+        oT[p] = u32x4{o0[0], o0[1], o1[0], o1[1]};
+      };
+      auto rd_img = [&](int sw) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          kT2[sw][p] = *reinterpret_cast<const u32x4*>(smem + G::KT_OFF + ((2 * kq + sw) * 2 + p) * 1024 + lane * 16);
+          const u32x2 lo = lds_read_tr16(img + sw * SCRB + p * SPART), hi2 = lds_read_tr16(img + sw * SCRB + p * SPART + 4 * SROW);
+          sT[sw][p] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
+        }
+      };
+      // MFMA steps
+      auto mS = [&](int kt, int jq, int j) {
+        if (H2P_ABL & 8) { if (j == 0) S[kt][jq] = negl[jq] + __builtin_bit_cast(f32x4, qA[jq][0]); return; }
+        S[kt][jq] = mfma_f16(qA[jq][j], kB[kt][j], j == 0 ? negl[jq] : S[kt][jq]); };      // large term first
+      auto mP = [&](int kt, int jq, int j) {      // (mutation test, bit 16: the cross product o0 v1 dropped, with its MFMA partner o1 v1)
+        if (H2P_ABL & 8) { if (j == 0) dP[kt][jq] = negd[jq] + __builtin_bit_cast(f32x4, oA[jq]); return; }
+        if (!((HDIFF_MUTANT & 16) && j == 1)) dP[kt][jq] = mfma_f16(oA[jq], vB[kt][j], j == 0 ? negd[jq] : dP[kt][jq]);
+      };
+      auto mV = [&](int kt, int j) {              // small terms first: o1 p0, o0 p1, o0 p0; (mutation test, bit 32: o1 p0 dropped)
+        if (H2P_ABL & 8) { if (j == 0) dVa[kt] += __builtin_bit_cast(f32x4, vec4(Pp[kt][0])) + __builtin_bit_cast(f32x4, vec4(Pp[kt][1])) + __builtin_bit_cast(f32x4, oT[0]) + __builtin_bit_cast(f32x4, oT[1]); return; }
+        if (!((HDIFF_MUTANT & 32) && j == 0)) dVa[kt] = mfma_f16(oT[j == 0 ? 1 : 0], vec4(Pp[kt][j == 1 ? 1 : 0]), dVa[kt]);
+      };
+      auto mK = [&](int kt, int j) {              // q1 s0, (q0 2^-8)(s1 2^8), q0 s0
+        if (H2P_ABL & 8) { if (j == 0) dKa[kt] += __builtin_bit_cast(f32x4, vec4(Sp[kt][0])) + __builtin_bit_cast(f32x4, vec4(Sp[kt][1])) + __builtin_bit_cast(f32x4, qT[0]) + __builtin_bit_cast(f32x4, qT[1]) + __builtin_bit_cast(f32x4, qTd); return; }
+        dKa[kt] = mfma_f16(j == 0 ? qT[1] : j == 1 ? qTd : qT[0], vec4(Sp[kt][j == 1 ? 1 : 0]), dKa[kt]);
+      };
+      auto mQ = [&](int sw, int j) {              // j 0: k0 s0 -> a; 1: (k1 2^8) s0 -> b; 2: k0 (s1 2^8) -> b
+        if (j == 0) acca = mfma_f16(kT2[sw][0], sT[sw][0], acca);
+        else accb = mfma_f16(kT2[sw][j == 1 ? 1 : 0], sT[sw][j == 1 ? 0 : 1], accb);
+      };
+      // vector steps of one (key tile, 16-query group): 4 scores per lane
+      auto cE = [&](int kt, int jq) {
+        if (H2P_ABL & 1) {
+#pragma unroll
+          for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+              Pp[kt][pc][2 * jq + w] = __builtin_bit_cast(unsigned, S[kt][jq][2 * w]) + pc;
+              Sp[kt][pc][2 * jq + w] = __builtin_bit_cast(unsigned, dP[kt][jq][2 * w + 1]) + pc;
+            }
+          return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pe[kt][jq][i] = __builtin_amdgcn_exp2f(S[kt][jq][i]);
+      };
+      auto cM = [&](int kt, int jq) {
+        if (H2P_ABL & 1) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ds[kt][jq][i] = pe[kt][jq][i] * dP[kt][jq][i];
+      };
+      auto cA = [&](int kt, int jq) {
+        if (H2P_ABL & 1) return; ds_split_a(ds[kt][jq][0], ds[kt][jq][1], ds[kt][jq][2], ds[kt][jq][3], dsdn, Sp[kt][0][2 * jq], Sp[kt][0][2 * jq + 1]); };
+      auto cB = [&](int kt, int jq) {
+        if (H2P_ABL & 1) return;
+        ds_split_b(ds[kt][jq][0], ds[kt][jq][1], ds[kt][jq][2], ds[kt][jq][3], dsdn, Sp[kt][0][2 * jq], Sp[kt][0][2 * jq + 1], rr[kt][jq][0], rr[kt][jq][1],
+                   rr[kt][jq][2], rr[kt][jq][3]);
+      };
+      auto cC = [&](int kt, int jq) {
+        if (H2P_ABL & 1) return;
+        unsigned h1a, h1b;
+        ds_split_c(rr[kt][jq][0], rr[kt][jq][1], rr[kt][jq][2], rr[kt][jq][3], up8, h1a, h1b);
+        if (HDIFF_MUTANT & 64) { h1a &= 0xffe0ffe0u; h1b &= 0xffe0ffe0u; }      // (mutation test, bit 64)
+        Sp[kt][1][2 * jq] = h1a; Sp[kt][1][2 * jq + 1] = h1b;
+      };
+      auto cP = [&](int kt, int jq) {
+        if (H2P_ABL & 1) return;
+        unsigned pa0, pa1, pb0, pb1;
+        split2(pe[kt][jq][0], pe[kt][jq][1], one, pa0, pa1);
+        split2(pe[kt][jq][2], pe[kt][jq][3], one, pb0, pb1);
+        Pp[kt][0][2 * jq] = pa0; Pp[kt][1][2 * jq] = pa1; Pp[kt][0][2 * jq + 1] = pb0; Pp[kt][1][2 * jq + 1] = pb1;
+      };
+      auto cW = [&](int kt, int jq) {
+        if (H2P_ABL & 16) return;             // (key i16 of tile kt, queries 16 jq + 4 g ..+3) into the wave's [key][query] image
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+          *reinterpret_cast<u32x2*>(scr + pc * SPART + kt * 16 * SROW + jq * 32 + swaddr) = u32x2{Sp[kt][pc][2 * jq], Sp[kt][pc][2 * jq + 1]};
+      };
+
+      if constexpr (DQ) { rd_img(0); acca = f32x4{0.f, 0.f, 0.f, 0.f}; accb = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      SLOT();
+      if constexpr (MAIN) {
+        mS(0, 0, 0); SLOT();
+        mP(0, 0, 0); SLOT();
+        mS(0, 0, 1); SLOT();
+        mP(0, 0, 1); SLOT();
+      }
+      // the slab floats of tile u - 2 (waves 4-7): thread -> floats tid - 256 (rows d < 8) and tid (rows d >= 8) of the [16 d][32 q] block
+      auto slab_out = [&](int r) {
+        if (!copier) {
+          float* pdst = part + (size_t)(u - 2) * (D * TQ) + (tid - 256) + 256 * r;
+          const float v = ((sraw[0] + sraw[1]) + sraw[2]) + sraw[3];
+          const float y = __builtin_ldexpf(v * a.inv_sqrt_d, dq_unscale);         // dQ_q 2^t_q: the reduce kernel gives c_q back
+          if constexpr (FIRST) *pdst = y;
+          else unsafeAtomicAdd(pdst, y);
+          if (r == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sraw[q] = xs0[8 * DQS + q * (G::PARTB / 4)];
+          }
+        }
+      };
+      if constexpr (SUM) { slab_out(0); SLOT(); }
+      if constexpr (MAIN) {
+        mS(0, 1, 0); cE(0, 0); SLOT();
+        mP(0, 1, 0); cM(0, 0); SLOT();
+        mS(0, 1, 1); cA(0, 0); rd_tr(0); SLOT();
+        mP(0, 1, 1); cB(0, 0); SLOT();
+      }
+      if constexpr (SUM) { slab_out(1); SLOT(); }
+      if constexpr (MAIN) {
+      }
+      if constexpr (DQ) {
+        mQ(0, 1); if constexpr (MAIN) cC(0, 0); SLOT();
+        mQ(0, 0); if constexpr (MAIN) cP(0, 0); SLOT();
+        mQ(0, 2); if constexpr (MAIN) { cW(0, 0); cE(0, 1); } rd_img(1); SLOT();
+      } else if constexpr (MAIN) { cC(0, 0); cP(0, 0); cW(0, 0); cE(0, 1); SLOT(); }
+      if constexpr (MAIN) {
+        mS(1, 0, 0); cM(0, 1); rd_tr(1); SLOT();
+        mP(1, 0, 0); cA(0, 1); SLOT();
+        mS(1, 0, 1); cB(0, 1); SLOT();
+        mP(1, 0, 1); cC(0, 1); SLOT();
+        mS(1, 1, 0); cP(0, 1); SLOT();
+        mP(1, 1, 0); cW(0, 1); qTd = down(qT[0]); SLOT();
+        mS(1, 1, 1); cE(1, 0); SLOT();
+        mP(1, 1, 1); cM(1, 0); SLOT();
+        if constexpr (PRE) { rd_rows(0, bnext); rd_rows(1, bnext); SLOT(); }
+        mV(0, 0); cA(1, 0); SLOT();
+        mK(0, 0); cB(1, 0); SLOT();
+        mV(0, 1); cC(1, 0); SLOT();
+        mK(0, 1); cP(1, 0); SLOT();
+        mV(0, 2); cW(1, 0); cE(1, 1); SLOT();
+        mK(0, 2); cM(1, 1); SLOT();
+      }
+      if constexpr (DQ) {
+        mQ(1, 1); if constexpr (MAIN) cA(1, 1); SLOT();
+        mQ(1, 0); if constexpr (MAIN) cB(1, 1); SLOT();
+        mQ(1, 2); if constexpr (MAIN) cC(1, 1); SLOT();
+      } else if constexpr (MAIN) { cA(1, 1); cB(1, 1); cC(1, 1); SLOT(); }
+      if constexpr (MAIN) {
+        cP(1, 1); SLOT();
+        cW(1, 1); mV(1, 0); SLOT();
+        mK(1, 0); SLOT();
+      }
+      if constexpr (DQ) {
+        float* pw = reinterpret_cast<float*>(smem + G::XP_OFF + (par ^ 1) * G::XPB + kq * G::PARTB);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[(4 * g + r) * DQS + 16 * ojq + i16] = __builtin_fmaf(accb[r], dnb, acca[r]);
+        SLOT();
+      }
+      if constexpr (MAIN) {
+        mV(1, 1); if constexpr (PRE) qA[0][1] = down(qA[0][0]); SLOT();
+        mK(1, 1); if constexpr (PRE) qA[1][1] = down(qA[1][0]); SLOT();
+        mV(1, 2); mK(1, 2); SLOT();
+      }
+      if constexpr (MAIN && DMA)
+        if (copier) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA runs of tile u + 1 have landed
+      if (H2P_ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else lds_barrier();
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    auto sweep = [&](auto first_tag) {
+      int b0 = 0, b1 = BUFB, b2 = 2 * BUFB;            // buffers of tiles u, u + 1, u + 2
+      auto rot = [&] { const int t = b0; b0 = b1; b1 = b2; b2 = t; };
+      //        main dq   sum  copy u+2  rows u+1
+      iteration(T{}, F{}, F{}, T{}, T{}, first_tag, 0, b0, b1, b2); rot();
+      iteration(T{}, T{}, F{}, T{}, T{}, first_tag, 1, b0, b1, b2); rot();
+      for (int u = 2; u < ntiles - 2; ++u) { iteration(T{}, T{}, T{}, T{}, T{}, first_tag, u, b0, b1, b2); rot(); }
+      iteration(T{}, T{}, T{}, F{}, T{}, first_tag, ntiles - 2, b0, b1, b2); rot();
+      iteration(T{}, T{}, T{}, F{}, F{}, first_tag, ntiles - 1, b0, b1, b2);
+      iteration(F{}, T{}, T{}, F{}, F{}, first_tag, ntiles, 0, 0, 0);
+      iteration(F{}, F{}, T{}, F{}, F{}, first_tag, ntiles + 1, 0, 0, 0);
+    };
+    if (kb == kb_begin) sweep(T{});
+    else sweep(F{});
+
+    // ---- dK, dV of this key block.  X = dK sqrt(d) 2^(sq + so + sv + 14 - DS_DOWN), Z = dV 2^(14 + so)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int key = key0 + kt * 16 + i16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = 4 * g + r;
+        kout[(size_t)d * L + key] = __builtin_ldexpf(dKa[kt][r] * a.inv_sqrt_d, -(P_UP - DS_DOWN<D> + so + sv + sq));
+        vout[(size_t)d * L + key] = __builtin_ldexpf(dVa[kt][r], -(P_UP + so));
+      }
+    }
+  }
+#undef SLOT
+}
+
+// dqkv[b][head * D + d][q] (Q third) = c_q x the sum over key ranges, in order, of the pipelined kernel's slabs [split][B][heads][L / 32][16][32]
+__global__ void mha_dq_reduce_h2p_kernel(const float* __restrict__ part, const __bf16* __restrict__ pieces, float* __restrict__ dqkv, int nsplit,
+                                         int C, int L, size_t split_stride) {
+  constexpr int D = 16, TQ = GeoP::TQ, Q4 = TQ / 4;
+  const int b = blockIdx.y, heads = C / D;
+  const size_t per_sample = (size_t)C * L;
+  const float* src = part + (size_t)b * per_sample;
+  float* dst = dqkv + (size_t)b * 3 * per_sample;
+  const size_t n4 = per_sample >> 2;
+  const int tiles = L / TQ;
+  const size_t piece_n = (size_t)L * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 acc = reinterpret_cast<const f32x4*>(src)[i];
+    for (int sp = 1; sp < nsplit; ++sp) acc += reinterpret_cast<const f32x4*>(src + (size_t)sp * split_stride)[i];
+    const int q4 = (int)(i % Q4), d = (int)((i / Q4) % D);
+    const size_t ht = i / ((size_t)Q4 * D);        // head * tiles + tile
+    const size_t head = ht / tiles, tile = ht - head * tiles;
+    const float* cq = reinterpret_cast<const float*>(pieces + (((size_t)b * heads + head) * S_COUNT + S_C) * piece_n);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(cq + tile * TQ + 4 * q4);
+    reinterpret_cast<f32x4*>(dst + (head * D + d) * (size_t)L + tile * TQ)[q4] = acc * c;
+  }
+}
+
 struct H2Geom { int nkb_total, per, nsplit; };
 H2Geom h2_geometry(int B, int heads, int L, int D) {
   H2Geom g;
@@ -821,7 +1271,7 @@ long long mha_bwd_slab_cap_bytes() {
   return cap;
 }
 
-// shapes the kernel covers: at least one 128-key block per CU -- below that (one sample at L <= 1024) the split pass and the
+// shapes the kernel covers: at least one 256-key block per CU (counted in 128-key units below, as the four-wave build did) -- below that (one sample at L <= 1024) the split pass and the
 // slab reduce cost more than the matrix core gains (56 vs 47 us at B = 1, L = 1024; 0.62 vs 0.94 ms at B = 4, L = 4096)
 bool mha_bwd_x3_shape_ok(int B, int C, int heads, int L) {
   const int D = C / heads;
@@ -832,15 +1282,35 @@ bool mha_bwd_x3_applicable(int B, int C, int heads, int L) {
 }
 
 // slabs (tile-major, one per key range: even a single range goes through the reduce kernel, which restores the [C][L] layout)
-// followed by the piece tensors (fifteen 2-byte piece slots per element, fourteen of them used) and the B * heads * 4 tensor maxima, in floats
+// followed by the piece tensors (S_COUNT = 17 two-byte piece slots per element: the enum above) and the B * heads * 4 tensor maxima, in floats
 int64_t mha_bwd_x3_workspace_floats(int B, int C, int heads, int L) {
   const H2Geom g = h2_geometry(B, heads, L, C / heads);
   const int64_t pieces_bytes = (int64_t)B * C * L * S_COUNT * 2;
   return (int64_t)g.nsplit * B * C * L + (pieces_bytes + 3) / 4 + 4 + (int64_t)B * heads * M_COUNT + 4;
 }
 
-// delta has been computed by the caller (mha_delta_kernel)
-void launch_mha_bwd_h2(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, float* ws,
+// More than 64 KB of LDS per workgroup has to be asked for -- per DEVICE (the attribute belongs to the device's copy of the kernel): asked
+// once per device of this process, remembered, and a refusal is reported to the caller BEFORE anything is launched.
+static bool big_lds_granted() {
+  constexpr int MAXDEV = 64;
+  static std::atomic<signed char> state[MAXDEV];      // 0: not asked yet, 1: granted, -1: refused
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return false;
+  signed char st = state[dev].load(std::memory_order_acquire);
+  if (st == 0) {
+    const bool ok =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_bwd_h2_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<16>::LDS_BYTES) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_bwd_h2_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_bwd_h2p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GeoP::LDS_BYTES) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    st = ok ? 1 : -1;
+    state[dev].store(st, std::memory_order_release);
+  }
+  return st > 0;
+}
+
+// delta has been computed by the caller (mha_delta_kernel).  false: the device refused the kernel's LDS size, nothing was launched
+bool launch_mha_bwd_h2(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, float* ws,
                        int B, int C, int heads, int L, hipStream_t stream) {
   const int D = C / heads;
   const H2Geom g = h2_geometry(B, heads, L, D);
@@ -861,23 +1331,25 @@ void launch_mha_bwd_h2(const float* qkv, const float* d_o, const float* lse2, co
   const dim3 mgrid(cdiv(L, 4096), M_COUNT * heads, B), sgrid(cdiv(L, THREADS), 4 * heads, B), grid(g.nsplit, heads, B);
   const size_t n4 = per_sample / 4;
   const int bx = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  if (!big_lds_granted()) return false;      // nothing has been enqueued yet: the caller runs the fp32-input backward instead
   (void)hipMemsetAsync(absmax, 0, (size_t)B * heads * M_COUNT * sizeof(unsigned), stream);
-  static const bool lds_ok = [] {      // more than 64 KB of LDS per workgroup has to be asked for, once per process
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_bwd_h2_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<16>::LDS_BYTES) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_bwd_h2_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES) == hipSuccess;
-  }();
-  (void)lds_ok;
   if (D == 16) {
     hipLaunchKernelGGL(mha_bwd_absmax_kernel<16>, mgrid, dim3(THREADS), 0, stream, qkv, d_o, absmax, C, L);
-    hipLaunchKernelGGL(mha_bwd_split_h2_kernel<16>, sgrid, dim3(THREADS), 0, stream, qkv, d_o, pieces, absmax, C, L, qscale, 1.0f);
-    hipLaunchKernelGGL(mha_bwd_h2_kernel<16>, grid, dim3(MTHREADS), Geo<16>::LDS_BYTES, stream, a);
-    hipLaunchKernelGGL(mha_dq_reduce_h2_kernel<16>, dim3(bx, B), dim3(256), 0, stream, ws, dqkv, g.nsplit, C, L, a.split_stride);
+    hipLaunchKernelGGL(mha_bwd_split_h2_kernel<16>, sgrid, dim3(THREADS), 0, stream, qkv, d_o, pieces, absmax, lse2, delta, C, L, qscale, 1.0f);
+    if (H2B_PIPE && MW == 8) {
+      hipLaunchKernelGGL(mha_bwd_h2p_kernel, grid, dim3(MTHREADS), GeoP::LDS_BYTES, stream, a);
+      hipLaunchKernelGGL(mha_dq_reduce_h2p_kernel, dim3(bx, B), dim3(256), 0, stream, ws, pieces, dqkv, g.nsplit, C, L, a.split_stride);
+    } else {
+      hipLaunchKernelGGL(mha_bwd_h2_kernel<16>, grid, dim3(MTHREADS), Geo<16>::LDS_BYTES, stream, a);
+      hipLaunchKernelGGL(mha_dq_reduce_h2_kernel<16>, dim3(bx, B), dim3(256), 0, stream, ws, dqkv, g.nsplit, C, L, a.split_stride);
+    }
   } else {
     hipLaunchKernelGGL(mha_bwd_absmax_kernel<32>, mgrid, dim3(THREADS), 0, stream, qkv, d_o, absmax, C, L);
-    hipLaunchKernelGGL(mha_bwd_split_h2_kernel<32>, sgrid, dim3(THREADS), 0, stream, qkv, d_o, pieces, absmax, C, L, qscale, 1.0f);
+    hipLaunchKernelGGL(mha_bwd_split_h2_kernel<32>, sgrid, dim3(THREADS), 0, stream, qkv, d_o, pieces, absmax, lse2, delta, C, L, qscale, 1.0f);
     hipLaunchKernelGGL(mha_bwd_h2_kernel<32>, grid, dim3(MTHREADS), Geo<32>::LDS_BYTES, stream, a);
     hipLaunchKernelGGL(mha_dq_reduce_h2_kernel<32>, dim3(bx, B), dim3(256), 0, stream, ws, dqkv, g.nsplit, C, L, a.split_stride);
   }
+  return true;
 }
 
 }  // namespace hdiff

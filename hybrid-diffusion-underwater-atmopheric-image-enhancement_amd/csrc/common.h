@@ -139,7 +139,7 @@ long long mha_bwd_slab_cap_bytes();                          // upper bound on t
 bool mha_bwd_x3_shape_ok(int B, int C, int heads, int L);     // the shape alone (mode-independent)
 bool mha_bwd_x3_applicable(int B, int C, int heads, int L);   // shape AND the bf16x3 contraction mode
 int64_t mha_bwd_x3_workspace_floats(int B, int C, int heads, int L);   // dQ slabs + piece tensors + maxima
-void launch_mha_bwd_h2(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, float* ws, int B,
+bool launch_mha_bwd_h2(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, float* ws, int B,
                        int C, int heads, int L, hipStream_t stream);
 // Attention forward in the split-operand mode.  attention_x3p.hip: d_head 32 on operands split ONCE into a workspace (fp16 pairs;
 // 0 bytes = shape not covered); attention_h2.hip: d_head 16 likewise, and the split passes of both; attention_x3.hip: the kernel that

@@ -7,7 +7,7 @@ import math
 import torch
 
 DEV = "cuda:0"
-CASES = ("plain", "loud-dO-pixel", "wide-V", "peaked", "tiny-dO")
+CASES = ("plain", "loud-dO-pixel", "wide-V", "peaked", "tiny-dO", "zero-dO-head", "dO-1e-30")
 
 
 def make_case(name, d, L, B, heads, g):
@@ -18,6 +18,10 @@ def make_case(name, d, L, B, heads, g):
     if name == "loud-dO-pixel": d_o[:, :, L // 3] *= 1e4                  # one position 1e4 x the rest: everything else sits 13 binades below the scale
     if name == "wide-V": qkv[:, 2 * Cc:] *= (2.0 ** torch.linspace(-15, 15, Cc))[None, :, None]     # V channels 2^30 apart
     if name == "tiny-dO": d_o *= 1e-20
+    if name == "dO-1e-30": d_o *= 1e-30                                  # the head's scale 2^so reaches 2^111: 2^(so + t_q) of a quiet row would leave fp32
+    if name == "zero-dO-head":                                            # a masked / zero-weight sample: one (sample, head) of dO all zero (so = 113),
+        d_o[0, 2 * d:3 * d] = 0.0                                         # and a run of silent positions inside a live head (t_q at its clamp of 24)
+        d_o[B - 1, :d, 100:200] = 0.0
     return qkv, d_o
 
 

@@ -257,6 +257,36 @@ def test_attention_backward_fp16_pairs_ranges(case, d):
             assert r2 <= 4.0 * r0, (case, name, b, h, r2, r0)
 
 
+@pytest.mark.parametrize("d", [16, 32])
+@pytest.mark.parametrize("case", ["zero-dO-head", "dO-1e-30"])
+def test_attention_backward_fp16_pairs_zero_and_vanishing_dO(case, d):
+    """dO is scaled by 2^so per (sample, head) and 2^t_q per query position; their PRODUCT left fp32 for a head whose
+    dO is all zero or below 2^-91 (so = 113, a silent row t_q = 24: 0 x inf = NaN in the staged pieces, NaN in dQ and dK of the whole
+    pair -- where autograd and the fp32-input kernel give 0).  The two factors are applied one after the other now.  A masked sample
+    (all-zero dO for one head, a run of silent positions in another) and dO x 1e-30: finite, exact zeros where the fp32 kernel has
+    exact zeros, and the fp32 kernel's values elsewhere (to 1e-5 of the tensor's magnitude: both are fp32-class)."""
+    import _attn_bwd_cases as K
+    from hdiff_amd import _capi
+    lib = _capi.lib()
+    heads, L, B = 8, 2048, 2
+    g = torch.Generator().manual_seed(19 + d)
+    qkv, d_o = K.make_case(case, d, L, B, heads, g)
+    qkv, d_o = qkv.to(DEV), d_o.to(DEV)
+    g32, gh2 = K.run_bwd(lib, qkv, d_o, heads, 0), K.run_bwd(lib, qkv, d_o, heads, 1)
+    assert torch.isfinite(gh2).all(), (case, d, "NaN / inf from the split-operand backward")
+    assert not torch.equal(gh2, g32), "the split-operand backward did not run"
+    Cc = heads * d
+    mag = g32.abs().max().item()
+    assert mag > 0
+    assert (gh2 - g32).abs().max().item() <= 1e-5 * mag, (case, d, (gh2 - g32).abs().max().item(), mag)
+    if case == "zero-dO-head":
+        for third in range(3):         # dQ, dK, dV of the silent head: exactly zero, like the fp32 kernel's
+            rows = slice(third * Cc + 2 * d, third * Cc + 3 * d)
+            assert g32[0, rows].abs().max().item() == 0.0
+            assert gh2[0, rows].abs().max().item() == 0.0, (case, d, third)
+        assert gh2[B - 1, :d, 100:200].abs().max().item() == 0.0          # dQ of the silent positions
+
+
 def test_attention_backward_slab_cap_setting():
     """HDIFF_BWD_SLAB_GIB (a deployment setting, read once per process: a fresh process here) caps the dQ partial slabs: with 1 GiB a
     B = 32, L = 8192, d_head 16 backward is cut into 8 key ranges per (sample, head) instead of the 16 the default 16 GiB allows -- a smaller
