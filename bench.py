@@ -52,6 +52,15 @@ BETA = (1e-4, 0.02)
 GUIDANCE_W = 1.8
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak (= fp32 vector peak)
 PEAK_BF16_MFMA_TFLOPS = 2516.6    # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+MFMA16_NS_AT_POWER_LIMIT = 8.1    # tools/mfma_k16_probe.hip (profiles/r06_attention_bwd_pipeline.txt (5)): a bare v_mfma_f32_16x16x32_f16 loop, two waves
+                                  # per SIMD, is clocked down to ~1.99 GHz by the board's power limit: 16.1 cycles = 8.1 ns per MFMA per SIMD
+N_SIMD = 1024                     # 256 CUs x 4
+# The headline is ONE sample of a box-to-box range (same build, different boxes of the pool: the kernel sits on the board's power limit and boxes
+# hold different clocks there).  Measured ranges of the round, updated with the round's records:
+BOX_RANGE = {"denoising_steps_per_s": [2.76, 3.00], "sclk_mhz_mean": [2159, 2315], "board_power_w_mean": [1319, 1331],
+             "what": "256x256, batch 8 headline on the boxes met in rounds 5-6 (lowest = a heat-soaked device right after the GPU suite)",
+             "source": "profiles/r05_bench_full_line*.json, profiles/r06_bench_full_line*.json"}
+SCLK_MAX_MHZ = 2400.0             # MI355X_MICROARCH.md: engine clock ceiling
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak (spec); ~6.3 TB/s is what a float4 copy achieves
 # algorithmic FLOPs per sample per UNet forward (torch flop counter on the reference UNet)
 FWD_GFLOP = {64: 74.0, 128: 529.6, 256: 5857.4, 512: 83254.1}
@@ -439,12 +448,12 @@ def source_hash(names):
 
 
 def load_traffic():
-    """(table, stamp): entries of profiles/roofline_traffic.json whose kernel sources still hash to what they were measured on."""
+    """(table, stamp, issue counts): entries of profiles/roofline_traffic.json whose kernel sources still hash to what they were measured on."""
     prof = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     try:
         tab = json.load(open(prof))
     except Exception:
-        return {}, {"status": "absent"}
+        return {}, {"status": "absent"}, {}
     stamp = tab.get("_stamp") or {}
     out, status = {}, {}
     for key, meta in (stamp.get("kernels") or {}).items():
@@ -456,8 +465,9 @@ def load_traffic():
         status[key] = "fresh" if fresh else "STALE (kernel source changed since the counters were collected): not reported"
         if fresh and key in tab:
             out[key] = tab[key]
+    issue = {k: v for k, v in (tab.get("_issue_counts") or {}).items() if k in out}      # instruction counts: only beside fresh traffic entries
     return out, {"measured_at_commit": stamp.get("commit"), "measured_utc": stamp.get("utc"),
-                 "collected_by": stamp.get("how"), "kernels": status}
+                 "collected_by": stamp.get("how"), "kernels": status}, issue
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -629,7 +639,7 @@ def main():
         durations[gname] = vals
 
     if rank == 0:
-        traffic_tab, traffic_stamp = load_traffic()
+        traffic_tab, traffic_stamp, issue_tab = load_traffic()
         flops_per_launch = 4.0 * L_full * L_full * Cc * (2 * B)          # QK^T + PV over 8 heads, 2B samples (CFG)
         roof = None
         att_ms = durations.get("attn") or []
@@ -652,6 +662,7 @@ def main():
                               f"heads=8 batch={2 * B}",
                     "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4),
+                    "frac_vs_16bit_peak": None if a.contract == "f32" else round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
                     "frac_vs_peak_div4_5": None if a.contract == "f32" else round(ach / (PEAK_BF16_MFMA_TFLOPS / 4.5), 4),
                     "frac_vs_peak_div6": None if a.contract == "f32" else round(ach / (PEAK_BF16_MFMA_TFLOPS / 6), 4),
                     "traffic": traffic_tab.get(f"mha_flash_fwd_L{L_full}_B{2 * B}" + ("" if a.contract == "f32" else "_bf16x3")),
@@ -660,6 +671,30 @@ def main():
                     "algorithmic_flop_per_launch": flops_per_launch,
                     "timed_in": "second pass of the same K steps as plain launches (HIP events on the launch stream)",
                     "secondary": []}
+            # What actually bounds the kernel: (a) the ISSUE model -- the kernel's own instruction counts from the PMC
+            # passes in profiles/ (per launch; valid while the kernel sources hash to what they were collected on) priced at 8 cycles per
+            # transcendental, 4 per other vector instruction, 8 of issue hold per MFMA, over 1024 SIMDs at the clock this run held; (b) the
+            # MATRIX-ONLY floor at the board's power limit -- the MFMA count at the rate a bare MFMA loop sustains on this board.
+            ic = issue_tab.get(f"mha_flash_fwd_L{L_full}_B{2 * B}" + ("" if a.contract == "f32" else "_bf16x3"))
+            roof.update({"issue_model_ms": None, "frac_vs_issue_model": None, "matrix_only_floor_ms_at_power_limit": None,
+                         "frac_vs_matrix_only_floor": None})      # filled when profiles/ holds instruction counts of THIS shape on THESE kernel sources
+            if ic:
+                mhz = (clock.summary().get("sclk_mhz_mean") or SCLK_MAX_MHZ)
+                valu, mfma, trans = ic["SQ_INSTS_VALU"], ic["SQ_INSTS_MFMA"], ic["SQ_INSTS_VALU_TRANS_F32"]
+                cyc = (8.0 * trans + 4.0 * (valu - mfma - trans) + 8.0 * mfma) / N_SIMD
+                issue_ms = cyc / (mhz * 1e3)
+                roof.update({"issue_model_ms": round(issue_ms, 2), "frac_vs_issue_model": round(issue_ms / avg, 4),
+                             "issue_model": {"formula": "(8 SQ_INSTS_VALU_TRANS_F32 + 4 (SQ_INSTS_VALU - SQ_INSTS_MFMA - TRANS) + 8 SQ_INSTS_MFMA) / 1024 SIMDs / sclk",
+                                             "sclk_mhz_used": mhz, "counts_per_launch": {k: ic[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_TRANS_F32")},
+                                             "mfma_coexec_over_busy": (round(ic["SQ_VALU_MFMA_COEXEC_CYCLES"] / ic["SQ_VALU_MFMA_BUSY_CYCLES"], 3)
+                                                                       if ic.get("SQ_VALU_MFMA_COEXEC_CYCLES") and ic.get("SQ_VALU_MFMA_BUSY_CYCLES") else None),
+                                             "counts_from": ic.get("from", "profiles/roofline_traffic.json _issue_counts")}})
+                if a.contract != "f32":
+                    floor_ms = mfma / N_SIMD * MFMA16_NS_AT_POWER_LIMIT * 1e-6
+                    roof.update({"matrix_only_floor_ms_at_power_limit": round(floor_ms, 2), "frac_vs_matrix_only_floor": round(floor_ms / avg, 4),
+                                 "bound_note": "energy: the kernel holds the board at its power limit (device_clock.board_power_w_mean) and the engine clock "
+                                               "below its 2400 MHz ceiling; schedules of the same instructions take the same wall time "
+                                               "(profiles/r06_attention_bwd_pipeline.txt)"})
             conv_ms = durations.get("conv3x3") or []
             if conv_ms:
                 avg = sum(conv_ms) / len(conv_ms)
@@ -697,14 +732,14 @@ def main():
             "metric": "denoising-steps/sec (256x256, T=1000)" if S == 256 else f"denoising-steps/sec ({S}x{S}, T=1000)",
             "value": world * K / elapsed, "unit": "denoising-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.contract == "f32" else "f32 (tensors and accumulation fp32; products of the attention scores (d_head 16: 2xfp16 pieces "
-                     "with a balance per term, d_head 32: 3xbf16 pieces), of attention's P.V and of the 3x3 convs behind GroupNorm as 2xfp16 "
-                     "pieces, on the 16-bit MFMA; "
+            "dtype": "f32" if a.contract == "f32" else "f32 (tensors and accumulation fp32; every operand of the attention contractions as 2xfp16 pieces -- scores: "
+                     "a balance per product term, four terms at d_head 16 / three at d_head 32; P.V: three terms -- and of the 3x3 convs behind "
+                     "GroupNorm likewise (other 3x3 convs: 3xbf16 pieces), on the 16-bit MFMA; "
                      "fp32-class error: golden suite green at the fp32 tolerances, per-kernel error vs float64 <= 1.25x (attention) / "
                      "1.5x (conv) the fp32-MFMA kernel's)",
             "data": "synthetic",
             "config": {"workload": f"CFG-DDPM sampling, {S}x{S}, T=1000 linear schedule (1e-4..0.02), w={GUIDANCE_W}, "
-                                   f"batch {B}/GPU (2x{B} UNet forwards per step), default UNet ch=128 ch_mult=[1,2,2,2] "
+                                   f"batch {B}/GPU (2x{B} UNet forwards per step; BASELINE's metric names no batch: 8 = the per-GPU batch of its config C5), default UNet ch=128 ch_mult=[1,2,2,2] "
                                    "num_res_blocks=2 (47.8 M params), random-init weights, in-kernel Philox noise",
                        "batch_per_gpu": B, "image": S, "launch": "plain launches" if a.eager else "hipGraph replay of the captured step",
                        "ms_per_step_plain_launches_with_events": None if kernel_pass_s is None else kernel_pass_s * 1e3,
@@ -714,6 +749,7 @@ def main():
                        "attention_contract": a.contract, "other_contract_mode": alt},
             "roofline": roof,
             "device_clock": clock.summary(),
+            "box_range": BOX_RANGE,
         }
     # everything below is outside the timed region and never enters `value`; N = 1 only
     if rank == 0 and world == 1:

@@ -21,7 +21,7 @@ from . import _capi
 from ._capi import build, lib
 
 __all__ = ["build", "lib", "install_dropin", "UNet", "GaussianDiffusionTrainer", "GaussianDiffusionSampler", "extract",
-           "set_contraction_mode", "get_contraction_mode"]
+           "set_contraction_mode", "get_contraction_mode", "reserve_split_workspace"]
 
 _CONTRACT = {"f32": 0, "bf16x3": 1}
 
@@ -29,15 +29,29 @@ _CONTRACT = {"f32": 0, "bf16x3": 1}
 def set_contraction_mode(mode: str) -> None:
     """How the attention and 3x3-convolution contractions run (process-wide; graphs captured afterwards keep the mode they saw).
 
-    ``"bf16x3"`` (default): every fp32 operand as three bf16 pieces (x = x0 + x1 + x2 exactly), the six products with
-    i + j <= 2 on the bf16 MFMA, fp32 accumulation -- fp32-class accuracy: the dropped terms are below 3 * 2^-24 relative,
-    the error against float64 is equal to or smaller than the fp32 kernels' (tests/test_gpu_ops.py) and the whole golden /
-    oracle suite passes in this mode at the fp32 tolerances (tests/conftest.py).  ``"f32"``: the fp32-input MFMA (an
-    exact k-ordered fma chain), about 1.35x slower per step at 256x256.  The environment variable ``HDIFF_CONTRACT`` sets
-    the initial value."""
+    ``"bf16x3"`` (default; the name is round 3's): the SPLIT-OPERAND mode -- every fp32 operand of a contraction is carried as 16-bit pieces
+    and the product as a few piece products on the 16-bit MFMA, each exact in the fp32 accumulator.  As shipped: every operand of the
+    attention contractions is an fp16 PAIR (x 2^s = h0 + h1: 22-23 of fp32's 24 bits) -- the scores with a balance per product term
+    (four terms at d_head 16, three at d_head 32: attention_h2.hip / attention_x3p.hip), P.V three terms, the backward's five products
+    likewise (attention_bwd_h2.hip) -- and so are both operands of the 3x3 convolutions behind GroupNorm + Swish; 3x3 convolutions
+    without a known input range and the 1x1 convolutions run on bf16 TRIPLES (x = x0 + x1 + x2 exactly, the six products with
+    i + j <= 2).  fp32-class accuracy: the error against float64 is <= 1.25x (attention) / 1.5x (conv) the fp32 kernels' rms
+    (tests/test_gpu_ops.py, tests/test_gpu_backward.py), the whole golden / oracle suite passes in this mode at the fp32 tolerances
+    (tests/conftest.py), mutants of each dropped-term class turn the gates red (tests/test_gpu_mutation.py).  ``"f32"``: the
+    fp32-input MFMA (an exact k-ordered fma chain), about 2.1x slower per step at 256x256.  The environment variable
+    ``HDIFF_CONTRACT`` sets the initial value."""
     if mode not in _CONTRACT:
         raise ValueError(f"contraction mode must be one of {sorted(_CONTRACT)}, got {mode!r}")
     _capi.check(lib().hdiff_set_contraction_mode(_CONTRACT[mode]), "set_contraction_mode")
+
+
+def reserve_split_workspace(flag: bool) -> None:
+    """Whether plans built from now on reserve the scratch of the split-operand attention kernels (default True: plans are keyed by shape,
+    not by mode).  ``False`` is for deployments that stay in the ``"f32"`` mode: it saves 18 bytes per qkv element per attention block
+    (engine.Plan.attention_workspace has the numbers); such a plan still runs correctly in the split-operand mode, on the slower
+    in-loop-split kernel."""
+    from . import engine
+    engine.RESERVE_SPLIT_WORKSPACE = bool(flag)
 
 
 def get_contraction_mode() -> str:

@@ -823,6 +823,9 @@ __global__ void mha_dq_reduce_h2_kernel(const float* __restrict__ part, float* _
 #define H2P_OPT 3             // switches of the pipelined kernel (A/B builds with -DH2P_OPT=<bits>): 1 static priority for waves 4-7 (the second-dispatched
 #endif                        // half loses every issue arbitration to its SIMD partner otherwise: -1.3 %), 2 no trailing s_nop in the dS split statements
                               // (the slot program puts an MFMA behind each: the partial-write hazard is covered; 0.0 %)
+#ifndef H2P_KTREG
+#define H2P_KTREG 0           // dev: 1 = the dq stage's k^T operands in 16 registers for the whole sweep instead of four LDS reads per tile (A/B)
+#endif
 #ifndef H2P_ABL
 #define H2P_ABL 0             // dev: timing ablations of the pipelined kernel (results wrong by construction): 1 no exp / split chain, 2 no dq stage,
 #endif                        // 4 no sum stage, 8 no main-phase MFMAs, 16 no dS image stores, 32 no barrier, 64 no tile copies, 128 no operand LDS reads
@@ -986,6 +989,13 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2p_kernel(const BwdH2Args a
     };
     rd_rows(0, 0); rd_rows(1, 0);
     qA[0][1] = down(qA[0][0]); qA[1][1] = down(qA[1][0]);
+    u32x4 kT2s[2][2];
+    if (H2P_KTREG) {
+#pragma unroll
+      for (int sw = 0; sw < 2; ++sw)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) kT2s[sw][p] = *reinterpret_cast<const u32x4*>(smem + G::KT_OFF + ((2 * kq + sw) * 2 + p) * 1024 + lane * 16);
+    }
 
     // One iteration = issue slots in a fixed order, fenced (sched_barrier) so that the order written here is the order issued: about one
     // MFMA and one group of ~4 vector instructions per slot (an MFMA holds the vector issue port for 8 of its 16 cycles; left to the scheduler
@@ -998,7 +1008,9 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2p_kernel(const BwdH2Args a
       const unsigned char* tb = smem + bcur;
       unsigned char* scr = smem + G::IMG_OFF + par * G::IMGB + wave * SCRB;
       const unsigned char* img = smem + G::IMG_OFF + (par ^ 1) * G::IMGB + (2 * kq) * SCRB + ojq * 32 + sraddr;      // source wave 2 kq (+ SCRB: 2 kq + 1)
-      u32x4 qT[2], oT[2], qTd, sT[2][2], kT2[2][2];
+      u32x4 qT[2], oT[2], qTd, sT[2][2];
+      u32x4 kT2l[2][2];
+      u32x4 (&kT2)[2][2] = H2P_KTREG ? kT2s : kT2l;
       f32x4 S[2][2], dP[2][2], acca, accb;
       unsigned Pp[2][2][4], Sp[2][2][4];          // [key tile][piece][word]: the B operands of dV^T / dK^T over the tile's 32 queries
       auto vec4 = [](const unsigned (&w)[4]) { return u32x4{w[0], w[1], w[2], w[3]}; };
@@ -1025,7 +1037,7 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2p_kernel(const BwdH2Args a
       auto rd_img = [&](int sw) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          kT2[sw][p] = *reinterpret_cast<const u32x4*>(smem + G::KT_OFF + ((2 * kq + sw) * 2 + p) * 1024 + lane * 16);
+          if (!H2P_KTREG) kT2[sw][p] = *reinterpret_cast<const u32x4*>(smem + G::KT_OFF + ((2 * kq + sw) * 2 + p) * 1024 + lane * 16);
           const u32x2 lo = lds_read_tr16(img + sw * SCRB + p * SPART), hi2 = lds_read_tr16(img + sw * SCRB + p * SPART + 4 * SROW);
           sT[sw][p] = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
         }

@@ -31,6 +31,9 @@ GN_EPS = 1e-5
 NUM_HEADS = 8       # ModelCondition.py:189
 
 
+RESERVE_SPLIT_WORKSPACE = True      # plans reserve the split-operand attention scratch (Plan.attention_workspace); hdiff_amd.reserve_split_workspace
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -317,7 +320,13 @@ class Plan:
         """Scratch for hdiff_mha_flash_fwd_ws (the operands as fp16 pieces, written and read inside that one call when the
         contraction mode is bf16x3): sized by the library from the SHAPE alone and allocated whatever the mode is now -- plans are
         keyed by shape, not by mode, and a plan first built in the f32 mode must not run the slower in-loop-split kernel once the
-        mode is switched (tests/test_gpu_end_to_end.py builds its plan in f32 and asserts the pre-split kernel ran)."""
+        mode is switched (tests/test_gpu_end_to_end.py builds its plan in f32 and asserts the pre-split kernel ran).
+        COST: 18 bytes per qkv element plus a small tail -- ~2.4 GB at B = 16, C = 128, L = 65 536 -- that a plan which only
+        ever runs in the f32 mode never touches.  A deployment that stays in f32 opts out BEFORE it builds its plans with
+        ``hdiff_amd.reserve_split_workspace(False)``; a plan built that way, run in the split-operand mode after all, falls back to the
+        in-loop-split kernel (correct, slower) -- the library decides per call from the pointer it is given."""
+        if not RESERVE_SPLIT_WORKSPACE:      # hdiff_amd.reserve_split_workspace(False): an f32-only deployment keeps the memory
+            return None
         need = C.c_int64(0)
         _capi.check(self.lib.hdiff_mha_flash_fwd_workspace(B, Cc, heads, L, C.byref(need)), "mha_flash_fwd_workspace")
         return self.buf((need.value + 3) // 4) if need.value > 0 else None

@@ -280,3 +280,38 @@ def test_sampler_runs_with_autograd_enabled_like_the_reference():
     with pytest.raises(RuntimeError, match="requires grad"):
         s(x.clone().requires_grad_(True), lab, noise_by_step=noise)
     assert sum(issubclass(r.category, RuntimeWarning) and "autograd enabled" in str(r.message) for r in rec) == 2      # once per instance
+
+
+def test_reserve_split_workspace_opt_out():
+    """plans reserve the split-operand attention scratch whatever the mode (18 bytes per qkv element).  An f32-only deployment
+    opts out with hdiff_amd.reserve_split_workspace(False) BEFORE building its plans: the attention calls then carry no workspace, the plan
+    holds less memory, and a run in the split-operand mode is still correct (the library takes the in-loop-split kernel for a null pointer)."""
+    import hdiff_amd
+    from hdiff_amd import engine
+    from hdiff_amd.DiffusionFreeGuidence.ModelCondition import UNet
+    cfg = dict(T=4, num_labels=2, ch=128, ch_mult=[1, 1], num_res_blocks=1, dropout=0.0)      # heads of 16 channels at L = 1024: the pre-split kernels' shapes
+    torch.manual_seed(0)
+    m = UNet(**cfg).eval().to(DEV)
+    x = torch.randn(2, 3, 32, 32, device=DEV); t = torch.tensor([1, 3], device=DEV); y = torch.tensor([1, 2], device=DEV)
+    before = hdiff_amd.get_contraction_mode()
+    try:
+        hdiff_amd.set_contraction_mode("bf16x3")
+        with torch.no_grad():
+            ref = m(x, t, y).clone()
+        with_ws = m.plan_for(2, 32, 32, torch.device(DEV)).plan
+        att = [a for n, _, a in with_ws.ops if n == "hdiff_mha_flash_fwd_ws"]
+        assert att and any(a[7] is not None for a in att)
+        bytes_with = with_ws.bytes_allocated()
+        hdiff_amd.reserve_split_workspace(False)
+        m2 = UNet(**cfg).eval().to(DEV)
+        m2.load_state_dict(m.state_dict())
+        with torch.no_grad():
+            out = m2(x, t, y)
+        lean = m2.plan_for(2, 32, 32, torch.device(DEV)).plan
+        assert all(a[7] is None and a[8].value == 0 for n, _, a in lean.ops if n == "hdiff_mha_flash_fwd_ws")
+        assert lean.bytes_allocated() < bytes_with
+        assert (out - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())      # another kernel of the same error class
+    finally:
+        hdiff_amd.reserve_split_workspace(True)
+        hdiff_amd.set_contraction_mode(before)
+        assert engine.RESERVE_SPLIT_WORKSPACE is True

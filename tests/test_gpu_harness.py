@@ -65,6 +65,13 @@ def test_bench_json_contract_small():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["launches_timed"] == 2 * 2 and r["avg_launch_ms"] > 0
     assert "kernels" in r["traffic_stamp"]
+    # the line says what bounds the kernel -- the algorithmic fraction of the raw 16-bit peak, the issue model made of the
+    # PMC instruction counts in profiles/ and the matrix-only floor at the power limit (None here: the counts are of the 256x256 shape), the box range
+    assert abs(r["frac_vs_16bit_peak"] - r["achieved"] / 2516.6) < 1e-3
+    for key in ("issue_model_ms", "frac_vs_issue_model", "matrix_only_floor_ms_at_power_limit", "frac_vs_matrix_only_floor"):
+        assert key in r, key
+    assert "denoising_steps_per_s" in d["box_range"] and "device_clock" in d
+    assert "2xfp16" in d["dtype"] and "three at d_head 32" in d["dtype"]                  # the shipped d_head 32 kernel: fp16 pairs, three terms
     assert d["config"]["attention_contract"] == "bf16x3" and "3xbf16" in d["dtype"]        # the library's default mode
     alt = d["config"]["other_contract_mode"]
     assert alt["contract"] == "f32" and alt["ms_per_step"] > 0

@@ -203,6 +203,12 @@ def test_psnr_ssim_definitions():
     assert 0 < p < 20 and -1 <= s <= 1
 
 
+def test_ssim_psnr_hand_computed_single_window():
+    """The hand-worked SSIM / PSNR values of tests/test_gpu_metrics.py (one 7x7 window, integers only) on the CPU suite too."""
+    import test_gpu_metrics as G
+    G.test_ssim_psnr_hand_computed_single_window()
+
+
 def test_tree_b_state_dict_layout_and_seeded_init_match_reference():
     """DynamicUNet (diffusion/Model.py): the 319 keys / shapes of the reference, and the same weights from the same seed."""
     from hdiff_amd.diffusion.Model import DynamicUNet

@@ -1,3 +1,5 @@
+# HISTORICAL (round 4).  Kept as the record behind profiles/r04_*; the current form of these passes is tools/profile_round.sh / tools/scripts/pmc_tcp.sh.
+# Since round 6 every profiler pass here runs under `timeout -k 10` and logs to <pass dir>.out / .err, as those do (a pass that hangs leaves a record).
 # Round 4's measurement script, tracked in round 5 as it was run then (profiles/r04_* name it).  Variant libraries (tools/bin/libhdiff_*.so:
 # build products, not tracked) are built with tools/scripts/ab_build.sh today; knobs this script sets through the environment may have
 # become compile-time -D switches of such a build since (tools/README.md).
@@ -11,4 +13,4 @@ TCP="TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP
 i=0
 # THE FOURTH SET -- eight derived TCP counters in ONE --pmc set -- is the pass that never returned in round 4 (profiles/r05_conv1x1_tcp.txt):
 # it is left out of the loop here; tools/scripts/pmc_tcp.sh collects those counters in sets of three under per-set timeouts.
-for set in "$SQ1" "$SQ2" "$SQ3"; do i=$((i+1)); rocprofv3 --pmc $set --kernel-trace --output-format csv -d $P/s$i -o pmc -- python3 tools/conv_once.py 16 128 384 256 1 > /dev/null 2>&1; python3 tools/pmc_summary.py $P/s$i/pmc_counter_collection.csv conv1x1_x3 2>&1; done
+for set in "$SQ1" "$SQ2" "$SQ3"; do i=$((i+1)); timeout -k 10 ${PMC_TIMEOUT:-240} rocprofv3 --pmc $set --kernel-trace --output-format csv -d $P/s$i -o pmc -- python3 tools/conv_once.py 16 128 384 256 1 > $P/s$i.out 2> $P/s$i.err || echo "pmc pass $P/s$i failed or timed out (rc $?): see $P/s$i.err"; python3 tools/pmc_summary.py $P/s$i/pmc_counter_collection.csv conv1x1_x3 2>&1; done

@@ -1,3 +1,5 @@
+# HISTORICAL (round 4).  Kept as the record behind profiles/r04_*; the current form of these passes is tools/profile_round.sh / tools/scripts/pmc_tcp.sh.
+# Since round 6 every profiler pass here runs under `timeout -k 10` and logs to <pass dir>.out / .err, as those do (a pass that hangs leaves a record).
 # Round 4's measurement script, tracked in round 5 as it was run then (profiles/r04_* name it).  Variant libraries (tools/bin/libhdiff_*.so:
 # build products, not tracked) are built with tools/scripts/ab_build.sh today; knobs this script sets through the environment may have
 # become compile-time -D switches of such a build since (tools/README.md).
@@ -6,7 +8,7 @@ P=gpurun_out/prof_d32fwd
 mkdir -p $P
 SQ1="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"
 SQ2="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES"
-rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $P/sq1 -o pmc -- python3 tools/attn_once.py 16 256 16384 > /dev/null 2>&1
-rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $P/sq2 -o pmc -- python3 tools/attn_once.py 16 256 16384 > /dev/null 2>&1
+timeout -k 10 ${PMC_TIMEOUT:-240} rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $P/sq1 -o pmc -- python3 tools/attn_once.py 16 256 16384 > $P/sq1.out 2> $P/sq1.err || echo "pmc pass $P/sq1 failed or timed out (rc $?): see $P/sq1.err"
+timeout -k 10 ${PMC_TIMEOUT:-240} rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $P/sq2 -o pmc -- python3 tools/attn_once.py 16 256 16384 > $P/sq2.out 2> $P/sq2.err || echo "pmc pass $P/sq2 failed or timed out (rc $?): see $P/sq2.err"
 for d in sq1 sq2; do python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv mha_flash_fwd_x3p; done
 python3 tools/attn_once.py 16 256 16384 2>&1 | grep fwd

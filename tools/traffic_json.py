@@ -22,7 +22,7 @@ ENTRIES = (
     ("conv3x3_128_256_B16", "igemm_kernel<2, 8, 12, 5, 1", "conv", False, ["conv_igemm.hip", "common.h"]),
     ("gn_stats_128_256_B16", "gn_stats_kernel", "gn", True, ["groupnorm.hip", "common.h"]),
     ("conv3x3_128_256_B16_pairs", "conv3x3_x3_kernel", "convh2", False, ["conv3x3_x3.hip", "conv_igemm.hip", "common.h"]),
-    ("mha_flash_bwd_L65536_B4_bf16x3", "mha_bwd_h2_kernel", "bwd", True, ["attention_bwd_h2.hip", "attention_bwd.hip", "common.h"]),
+    ("mha_flash_bwd_L65536_B4_bf16x3", "mha_bwd_h2p_kernel", "bwd", True, ["attention_bwd_h2.hip", "attention_bwd.hip", "common.h"]),
     ("mha_flash_bwd_L65536_B4", "bwd_fused", "bwdf32", True, ["attention_bwd.hip", "common.h"]),
 )
 ALGORITHMIC = {
@@ -66,6 +66,19 @@ def main():
             continue
         tab["_raw_KiB"][key] = {"FETCH_SIZE": f, "WRITE_SIZE": w, "fetch_doubled": wide}
         tab[key] = int(((2 if wide else 1) * f + w) * 1024)
+    # instruction counts per dispatch (the SQ passes <prefix>_sq1 / _sq2 of profile_round.sh): what bench.py's issue model is made of
+    tab["_issue_counts"] = {}
+    for key, flt, pre, _, _ in ENTRIES:
+        try:
+            c1 = mean_counter(os.path.join(prof, f"{pre}_sq1", "pmc_counter_collection.csv"), flt)
+            c2 = mean_counter(os.path.join(prof, f"{pre}_sq2", "pmc_counter_collection.csv"), flt)
+        except OSError:
+            continue
+        if "SQ_INSTS_VALU" in c1 and "SQ_INSTS_MFMA" in c1 and "SQ_INSTS_VALU_TRANS_F32" in c2:
+            tab["_issue_counts"][key] = {"SQ_INSTS_VALU": c1["SQ_INSTS_VALU"], "SQ_INSTS_MFMA": c1["SQ_INSTS_MFMA"],
+                                         "SQ_INSTS_VALU_TRANS_F32": c2["SQ_INSTS_VALU_TRANS_F32"],
+                                         "SQ_VALU_MFMA_BUSY_CYCLES": c1.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+                                         "SQ_VALU_MFMA_COEXEC_CYCLES": c2.get("SQ_VALU_MFMA_COEXEC_CYCLES")}
     tab["_stamp"] = stamp(commit, f"tools/profile_round.sh -> {prof} (separate --pmc FETCH_SIZE / WRITE_SIZE passes with --kernel-trace only)")
     tab["_note"] = ("FETCH_SIZE counts the L2's fabric-side read requests, Infinity-Cache hits included: an upper bound on HBM bytes.")
     json.dump(tab, open(out, "w"), indent=1)
