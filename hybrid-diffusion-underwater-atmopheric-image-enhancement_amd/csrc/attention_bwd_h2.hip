@@ -824,8 +824,8 @@ __global__ void mha_dq_reduce_h2_kernel(const float* __restrict__ part, float* _
 #endif                        // half loses every issue arbitration to its SIMD partner otherwise: -1.3 %), 2 no trailing s_nop in the dS split statements
                               // (the slot program puts an MFMA behind each: the partial-write hazard is covered; 0.0 %)
 #ifndef H2P_KTREG
-#define H2P_KTREG 0           // dev: 1 = the dq stage's k^T operands in 16 registers for the whole sweep instead of four LDS reads per tile (A/B)
-#endif
+#define H2P_KTREG 1           // 1 = the dq stage's k^T operands in 16 registers for the whole sweep (the steady loop has no spill with them; -1.3 %),
+#endif                        // 0 = four LDS reads per tile out of a copy in MFMA operand order (A/B)
 #ifndef H2P_ABL
 #define H2P_ABL 0             // dev: timing ablations of the pipelined kernel (results wrong by construction): 1 no exp / split chain, 2 no dq stage,
 #endif                        // 4 no sum stage, 8 no main-phase MFMAs, 16 no dS image stores, 32 no barrier, 64 no tile copies, 128 no operand LDS reads

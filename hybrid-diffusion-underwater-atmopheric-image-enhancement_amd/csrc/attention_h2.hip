@@ -59,6 +59,9 @@ namespace {
 #ifndef H2_DIAG
 #define H2_DIAG 0       // diagnostic build: s_memtime / s_memrealtime around the tile loop (tools/h2w_clock.py); never set in the product
 #endif
+#ifndef H2_T4
+#define H2_T4 1       // dev: 0 = the fourth score term k1 q1 (2^-24 of a score) multiplied by ZEROS -- same MFMAs, a quarter of the score product's
+#endif                // multipliers idle (A/B for the energy of the kernel at the board's power limit; tools/scripts/r6_fwd_t4.sh)
 #ifndef H2_VALU_PER_STAGE
 #define H2_VALU_PER_STAGE 54
 #endif
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(THREADS, 2) void mha_flash_fwd_h2_kernel(const __bf
       // (asm: written as four v2f16 multiplications in C, hipcc 7.2 -O3 emits ONE v_pk_mul_f16 and broadcasts word 0 over the tuple)
       unsigned dnw[4];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) asm("v_pk_mul_f16 %0, %1, %2" : "=v"(dnw[w]) : "v"(sel[w]), "v"(dn2));
+      for (int w = 0; w < 4; ++w) asm("v_pk_mul_f16 %0, %1, %2" : "=v"(dnw[w]) : "v"(sel[w]), "v"((!H2_T4 && hi) ? 0u : dn2));
       qop[qt][0] = sel;                                      // against K set 0 = (k0 | k0 2^-8)
       qop[qt][1] = u32x4{dnw[0], dnw[1], dnw[2], dnw[3]};    // against K set 1 = (k1 2^8 | k1)
     }
