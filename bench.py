@@ -262,7 +262,8 @@ def train_steps(size, batch, steps, warmup, dropout, dev, rank=0, world=1, rehea
     parallel.broadcast_parameters_(m.parameters())
     tr = GaussianDiffusionTrainer(m, BETA[0], BETA[1], MODEL["T"]).to(dev)
     weights = list(m.parameters())
-    opt = torch.optim.AdamW(weights, lr=1e-4, weight_decay=1e-4)
+    from hdiff_amd import optim as hdiff_optim
+    opt = hdiff_optim.AdamW(weights, lr=1e-4, weight_decay=1e-4)      # the native tail: clip + AdamW in three launches (csrc/optimizer.hip)
     flat = parallel.FlatGradients(weights, world, overlap=True) if world > 1 else None
     g = torch.Generator().manual_seed(1 + rank)              # per-rank data
     x0 = (torch.rand(batch, 3, size, size, generator=g) * 2 - 1).to(dev)
@@ -281,9 +282,7 @@ def train_steps(size, batch, steps, warmup, dropout, dev, rank=0, world=1, rehea
         loss.backward()
         if flat is not None:
             exchanged = flat.exchange_mean_()
-        gn = torch.nn.utils.clip_grad_norm_(weights, 1.0)
-        opt.step()
-        return gn
+        return opt.step(max_grad_norm=1.0)                        # clip_grad_norm_(weights, 1.0); AdamW.step()
 
     torch.cuda.reset_peak_memory_stats(dev)
     for _ in range(warmup):

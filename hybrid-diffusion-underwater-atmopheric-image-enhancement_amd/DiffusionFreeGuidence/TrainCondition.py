@@ -22,6 +22,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader, Subset
 
+from .. import optim as hdiff_optim
 from .. import parallel
 from ..Scheduler import GradualWarmupScheduler
 from ..imageio import ImageDomainFolder, SyntheticDomains, save_image
@@ -106,7 +107,9 @@ def train(modelConfig: Dict) -> List[float]:
         print("Model weight load down.")
     parallel.broadcast_parameters_(net.parameters())
     weights = list(net.parameters())
-    opt = torch.optim.AdamW(weights, lr=cfg["lr"], weight_decay=WEIGHT_DECAY)
+    # AdamW(lr, weight_decay = 1e-4) as the reference builds it (TrainCondition.py:39-40): on the GPU the native optimizer, which takes the clip of
+    # :61-62 into the same three launches (hdiff_amd/optim.py); the class is a torch.optim.Optimizer, the schedulers below drive it unchanged
+    opt = hdiff_optim.AdamW(weights, lr=cfg["lr"], weight_decay=WEIGHT_DECAY)
     flat_grads = parallel.FlatGradients(weights, world, overlap=True) if world > 1 else None   # views of one exchange buffer; bucket reduce-scatters start during backward
     schedule = GradualWarmupScheduler(
         optimizer=opt, multiplier=cfg["multiplier"], warm_epoch=cfg["epoch"] // 10,
@@ -136,8 +139,7 @@ def train(modelConfig: Dict) -> List[float]:
             loss.backward()
             if flat_grads is not None:
                 flat_grads.exchange_mean_()                        # the one collective of a step (mean over ranks)
-            torch.nn.utils.clip_grad_norm_(weights, cfg["grad_clip"])
-            opt.step()
+            opt.step(max_grad_norm=cfg["grad_clip"])               # clip_grad_norm_(weights, grad_clip); opt.step()
             losses.append(loss.item())
             if hasattr(progress, "set_postfix"):
                 progress.set_postfix(ordered_dict={"epoch": epoch, "loss: ": losses[-1], "img shape: ": tuple(x_0.shape),

@@ -130,6 +130,10 @@ _PROTOS = {
     "hdiff_concat2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "hdiff_clip": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_void_p]),
     "hdiff_axpby": (C.c_int, [C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hdiff_opt_chunk": (C.c_int, []),
+    "hdiff_grad_norm_clip_coef": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "hdiff_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   C.c_int64, C.c_void_p]),
     "hdiff_randn": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "hdiff_graph_begin": (C.c_int, [C.c_void_p]),
     "hdiff_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -26,7 +26,7 @@ int contraction_mode() {
 
 extern "C" {
 
-int hdiff_abi_version(void) { return 5; }   // 3: hdiff_q_sample takes the schedule length, hdiff_mha_flash_bwd a workspace; 4: hdiff_mha_flash_fwd_ws, hdiff_ddpm_step takes the schedule length; 5: hdiff_conv_desc.wp_h2 / act_scale, hdiff_pack_conv_weight_h2, hdiff_gn_act_scale
+int hdiff_abi_version(void) { return 6; }   // 6: hdiff_opt_chunk, hdiff_grad_norm_clip_coef, hdiff_adamw_step (the optimizer tail); 3: hdiff_q_sample takes the schedule length, hdiff_mha_flash_bwd a workspace; 4: hdiff_mha_flash_fwd_ws, hdiff_ddpm_step takes the schedule length; 5: hdiff_conv_desc.wp_h2 / act_scale, hdiff_pack_conv_weight_h2, hdiff_gn_act_scale
 const char* hdiff_last_error(void) { return hdiff::g_err; }
 
 int hdiff_set_contraction_mode(int mode) {

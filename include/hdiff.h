@@ -341,6 +341,22 @@ int hdiff_concat2(const float* a, const float* b, float* out, int B, int64_t n0,
 int hdiff_clip(const float* x, float* y, float lo, float hi, int64_t n, hdiff_stream_t stream);
 /* out = a*x + b*y (y may be NULL): bias merges and other weight-preparation arithmetic */
 int hdiff_axpby(float a, const float* x, float b, const float* y, float* out, int64_t n, hdiff_stream_t stream);
+
+/* (ABI 6) The tail of an optimizer step over a LIST of tensors, replacing the caller's torch.nn.utils.clip_grad_norm_(params, grad_clip) and
+ * torch.optim.AdamW.step() (reference call sites: DiffusionFreeGuidence/TrainCondition.py:61-63, :39-40).  `table` (device) holds one entry per
+ * tensor; `chunks` (device, 2 ints per chunk: tensor index, chunk index inside the tensor) cuts the work into pieces of hdiff_opt_chunk()
+ * elements -- both built once by the host.  Pointers need 4-byte alignment only.
+ *   hdiff_grad_norm_clip_coef: partial[nchunks] scratch; norm_coef[0] = sqrt(sum g^2) over all tensors (fixed summation order, float64 final
+ *                              sum), norm_coef[1] = min(1, max_norm / (norm + 1e-6)).
+ *   hdiff_adamw_step:          g *= norm_coef[1] (in place, skipped when norm_coef is NULL); p *= 1 - lr wd; m += (g - m)(1 - beta1);
+ *                              v = beta2 v + (1 - beta2) g^2; p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ *                              (torch.optim.AdamW's single-tensor formulas in its order of operations; step counts from 1). */
+typedef struct { float* p; float* g; float* m; float* v; long long n; } hdiff_opt_tensor;
+int hdiff_opt_chunk(void);
+int hdiff_grad_norm_clip_coef(const hdiff_opt_tensor* table, const int* chunks, int nchunks, float* partial, float max_norm,
+                              float* norm_coef, hdiff_stream_t stream);
+int hdiff_adamw_step(const hdiff_opt_tensor* table, const int* chunks, int nchunks, const float* norm_coef, double lr, double beta1,
+                     double beta2, double eps, double weight_decay, int64_t step, hdiff_stream_t stream);
 /* nn.Dropout (train mode, ModelCondition.py:185): keep-mask scaled by 1/keep from the Philox stream, and out = a*b */
 int hdiff_dropout_mask(float* out, int64_t n, float keep, uint64_t seed, uint64_t offset, hdiff_stream_t stream);
 int hdiff_mul(const float* a, const float* b, float* out, int64_t n, hdiff_stream_t stream);

@@ -347,9 +347,11 @@ def T(a):
     return torch.from_numpy(np.asarray(a))
 
 
-def test_trainer_gradients_and_adamw_step_golden():
+@pytest.mark.parametrize("native_tail", [False, True])
+def test_trainer_gradients_and_adamw_step_golden(native_tail):
     """Reference: loss = trainer(x_0, labels).sum() / b**2; backward; clip_grad_norm_(1.0); AdamW step
-    (TrainCondition.py:59-63), recorded from the real reference in tests/golden/trainer_small.npz."""
+    (TrainCondition.py:59-63), recorded from the real reference in tests/golden/trainer_small.npz.  native_tail: the clip and the
+    AdamW step by hdiff_amd.optim.AdamW (csrc/optimizer.hip) instead of torch's calls -- the same recorded norm and parameters."""
     u, d = load("unet_small.npz"), load("trainer_small.npz")
     c = json.loads(bytes(u["cfg_json"]).decode())
     m = MC.UNet(**c)
@@ -357,7 +359,8 @@ def test_trainer_gradients_and_adamw_step_golden():
     m = m.to(DEV).train()
     b1, bT = [float(v) for v in d["beta"]]
     tr = DC.GaussianDiffusionTrainer(m, b1, bT, c["T"]).to(DEV)
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-4)
+    from hdiff_amd import optim as HO
+    opt = (HO.AdamW if native_tail else torch.optim.AdamW)(m.parameters(), lr=1e-4, weight_decay=1e-4)
     opt.zero_grad()
     x_0 = T(d["x_0"]).to(DEV)
     loss = tr(x_0, T(d["labels"]).to(DEV), t=T(d["t"]).to(DEV), noise=T(d["noise"]).to(DEV))
@@ -374,9 +377,12 @@ def test_trainer_gradients_and_adamw_step_golden():
         worst = max(worst, err)
         print(f"grad {name}: rel err {err:.2e}")
         assert err < 1e-3, (name, err)
-    total = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0).item()
+    if native_tail:
+        total = opt.step(max_grad_norm=1.0).item()
+    else:
+        total = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0).item()
+        opt.step()
     assert abs(total - float(d["grad_total_norm"][0])) / float(d["grad_total_norm"][0]) < 1e-3
-    opt.step()
     for key in [k for k in d.files if k.startswith("after_step/")]:
         name = key[11:]
         # first AdamW step moves every element by ~lr * g / (|g| + eps): where the clipped gradient is ~1e-8 = eps the

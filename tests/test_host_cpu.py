@@ -26,7 +26,7 @@ def header_symbols():
 
 def test_library_exports_every_declared_symbol():
     lib = hdiff_amd.lib()
-    assert lib.hdiff_abi_version() == 5
+    assert lib.hdiff_abi_version() == 6
     syms = header_symbols()
     assert len(syms) >= 25
     out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
@@ -394,7 +394,8 @@ def test_roofline_traffic_table_is_stamped_and_goes_stale_with_the_kernel_source
     bench.load_traffic() reports an entry only while the sources' CODE (comments and whitespace stripped) still hashes to that (a
     stale counter is not a measurement of the run that prints it)."""
     import bench
-    table, stamp = bench.load_traffic()
+    table, stamp, issue = bench.load_traffic()
+    assert set(issue) <= set(table)                      # instruction counts are reported only beside fresh traffic entries
     assert stamp.get("measured_at_commit") and stamp.get("measured_utc")
     assert set(stamp["kernels"]) >= {"mha_flash_fwd_L65536_B16", "mha_flash_fwd_L65536_B16_bf16x3", "gn_stats_128_256_B16"}
     for key, state in stamp["kernels"].items():
@@ -407,12 +408,13 @@ def test_roofline_traffic_table_is_stamped_and_goes_stale_with_the_kernel_source
     with open(fake / "attention.hip", "a") as fh:
         fh.write("// edited\n\n/* a block\n   comment */\n")
     monkeypatch.setattr(bench, "CSRC", str(fake))
-    table_c, stamp_c = bench.load_traffic()
+    table_c, stamp_c, _ = bench.load_traffic()
     assert stamp_c["kernels"]["mha_flash_fwd_L65536_B16"] == stamp["kernels"]["mha_flash_fwd_L65536_B16"]
     # (... a changed token does not)
     with open(fake / "attention.hip", "a") as fh:
         fh.write("static int edited_marker = 1;\n")
-    table2, stamp2 = bench.load_traffic()
+    table2, stamp2, issue2 = bench.load_traffic()
+    assert "mha_flash_fwd_L65536_B16" not in issue2
     assert "mha_flash_fwd_L65536_B16" not in table2 and stamp2["kernels"]["mha_flash_fwd_L65536_B16"].startswith("STALE")
     if stamp["kernels"]["gn_stats_128_256_B16"] == "fresh":
         assert "gn_stats_128_256_B16" in table2

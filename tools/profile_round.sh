@@ -81,7 +81,7 @@ if want summary; then
 {
   for d in x3_sq1 x3_sq2; do echo "## $d: rocprofv3 --pmc ... -- python3 tools/attn_once.py 16   (bf16x3 mode: split passes + mha_flash_fwd_h2_kernel<16, 4>; rocprofv3 prints that name mangled: its demangler does not know __bf16)"; python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv "mha_flash_fwd_h2_kernel"; done
   echo "## attn_sq1: HDIFF_CONTRACT=f32 ... -- python3 tools/attn_once.py 16"; python3 tools/pmc_summary.py $P/attn_sq1/pmc_counter_collection.csv "fast_kernel<16"
-  for d in bwd_sq1 bwd_sq2; do echo "## $d: ... -- python3 tools/attn_bwd_once.py 4   (bf16x3 mode: maxima + split pass + mha_bwd_h2_kernel<16> + slab reduce)"; python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv mha_bwd_h2_kernel; done
+  for d in bwd_sq1 bwd_sq2; do echo "## $d: ... -- python3 tools/attn_bwd_once.py 4   (bf16x3 mode: maxima + split pass + mha_bwd_h2p_kernel (round 6: the pipelined d_head 16 kernel) + slab reduce)"; python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv mha_bwd_h2p_kernel; done
   for d in bwd32_sq1 bwd32_sq2; do echo "## $d: ... -- python3 tools/attn_bwd_once.py 4 256 16384   (d_head 32, L = 16384: mha_bwd_h2_kernel<32>)"; python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv mha_bwd_h2_kernel; done
   for d in fwd32_sq1 fwd32_sq2; do echo "## $d: ... -- python3 tools/attn_once.py 16 256 16384   (d_head 32 forward, L = 16384: mha_flash_fwd_x3p_kernel, fp16 pairs)"; python3 tools/pmc_summary.py $P/$d/pmc_counter_collection.csv mha_flash_fwd_x3p; done
   echo "## bwdf32_sq1: HDIFF_CONTRACT=f32 ... -- python3 tools/attn_bwd_once.py 4"; python3 tools/pmc_summary.py $P/bwdf32_sq1/pmc_counter_collection.csv mha_bwd_fused
