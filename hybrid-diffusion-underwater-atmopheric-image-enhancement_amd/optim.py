@@ -47,9 +47,10 @@ class AdamW(torch.optim.Optimizer):
         n = sum(p.numel() for p in need)
         m_flat, v_flat = torch.zeros(n, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
+        shared_step = torch.tensor(0.0)      # ONE step counter object for the parameters that start together (incremented once per step)
         for p in need:
             st = self.state[p]
-            st["step"] = torch.tensor(0.0)
+            st["step"] = shared_step
             st["exp_avg"] = m_flat[off:off + p.numel()].view_as(p)
             st["exp_avg_sq"] = v_flat[off:off + p.numel()].view_as(p)
             off += p.numel()
@@ -120,15 +121,20 @@ class AdamW(torch.optim.Optimizer):
         for group, (_, t_dev, c_dev, n, ps) in zip(self.param_groups, tables):
             if n == 0:
                 continue
-            steps = {int(self.state[p]["step"].item()) if torch.is_tensor(self.state[p]["step"]) else int(self.state[p]["step"]) for p in ps}
+            counters = {id(self.state[p]["step"]): self.state[p]["step"] for p in ps}      # distinct counter objects (one, unless states were loaded)
+            steps = {int(c.item()) if torch.is_tensor(c) else int(c) for c in counters.values()}
             if len(steps) != 1:
                 raise RuntimeError("hdiff_amd.optim.AdamW: the parameters of a group must have taken the same number of steps")
             step = steps.pop() + 1
             b1, b2 = group["betas"]
             _capi.check(self._lib.hdiff_adamw_step(t_dev.data_ptr(), c_dev.data_ptr(), n, coef_ptr, float(group["lr"]), float(b1), float(b2),
                                                    float(group["eps"]), float(group["weight_decay"]), step, stream), "adamw_step")
-            for p in ps:
-                self.state[p]["step"] = torch.tensor(float(step))
+            if all(torch.is_tensor(c) for c in counters.values()):
+                for c in counters.values():
+                    c.fill_(float(step))
+            else:
+                for p in ps:
+                    self.state[p]["step"] = torch.tensor(float(step))
         if max_grad_norm is not None:
             return self._norm_coef[0].clone()
         return loss
