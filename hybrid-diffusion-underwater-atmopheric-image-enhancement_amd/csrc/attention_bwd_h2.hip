@@ -805,16 +805,18 @@ __global__ void mha_dq_reduce_h2_kernel(const float* __restrict__ part, float* _
 // the slab adds, with the matrix AND the vector pipe idle on every SIMD at once (the dQ output path: 23 % of the launch).
 // Here the three pieces of a tile's work run in three consecutive iterations, each between the same two barriers as the MAIN phase of a
 // later tile, so their latencies hide under its instruction stream:
-//   iteration u:   main(u)   S', dP', P', dS', dV^T, dK^T of tile u from tile buffer u & 1; dS' images -> image set u & 1
+//   iteration u:   main(u)   S', dP', P', dS', dV^T, dK^T of tile u from tile buffer u % 3; dS' images -> image set u & 1
 //                  dq(u - 1) dQ'^T of tile u - 1 contracted across the workgroup out of image set (u - 1) & 1 (complete since the last
 //                            barrier): wave w = (key quarter w >> 1, 16-query group w & 1), partial tile -> xpart[(u - 1) & 1]
 //                  sum(u - 2) the four key quarters of tile u - 2 summed out of xpart[u & 1], unscaled, to the slab (store / L2 float add)
-//                  LDS-DMA of tile u + 1 into tile buffer (u + 1) & 1 (last read before the previous barrier)
+//                  LDS-DMA of tile u + 2 into tile buffer (u + 2) % 3 (last read before the previous barrier); the ROW operands and chain starts of
+//                  tile u + 1 (in LDS since the barrier before) are read behind the last MFMA that uses tile u's: the next iteration opens with an MFMA
 //   barrier
 // Nothing per query is needed after the main phase: the two chain starts (14 - lse2, -delta') come per tile from the split pass and the factor
-// c_q = 2^-t_q is given back by the slab reduce kernel (a power of two: exact), so a tile buffer can be overwritten one iteration after its
-// main phase.  Same operand formats, same products, same summation order inside a tile as the kernel above; dQ's key-quarter partials
-// are summed in a fixed order: bitwise reproducible.
+// c_q = 2^-t_q is given back by the slab reduce kernel (a power of two: exact).  Same operand formats, same products, same summation order
+// inside a tile as the kernel above; dQ's key-quarter partials are summed in a fixed order: bitwise reproducible.
+// What it bought (profiles/r06_pmc_summary.txt, r06_attention_bwd_pipeline.txt): 7.5 % fewer cycles, co-execution 0.25 -> 0.41 -- and 1-2 % of
+// wall time, because the board is on its power limit and returns the cycles as clock: the kernel is bound by the energy of its instructions.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef H2B_PIPE
 #define H2B_PIPE 1            // dev: 0 = d_head 16 on the two-barrier kernel above (A/B)

@@ -1,5 +1,5 @@
 """Dev tool (round 6): what clock and board power does ONE hot kernel hold when it runs back to back?
-  python tools/kernel_power.py bwd16|bwd32|fwd16|fwd32 [batch] [seconds]
+  python tools/kernel_power.py bwd16|bwd32|fwd16|fwd32|conv3 [batch] [seconds]      (conv3: the 128 -> 128 3x3 convolution at 256x256 behind GroupNorm, fp16 pairs)
 Runs the launch in a loop for `seconds` (default 4) after a 1 s warm-up, samples the engine clock and the board power from sysfs at
 20 Hz (bench.ClockSampler), prints ms per launch, MHz and W.  A kernel that sits on the board's power limit trades cycles for clock:
 an instruction-count saving then shows as a higher clock at the same wall time -- read this BEFORE believing a cycle model."""
@@ -19,11 +19,34 @@ s = torch.cuda.current_stream().cuda_stream
 what = sys.argv[1] if len(sys.argv) > 1 else "bwd16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else (16 if what.startswith("fwd") else 4)
 secs = float(sys.argv[3]) if len(sys.argv) > 3 else 4.0
+if what == "conv3":
+    import math
+    from hdiff_amd import engine as E
+    Cin = Cout = 128; S = 256
+    x = torch.randn(B, Cin, S, S, device="cuda")
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda") / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, device="cuda")
+    plan = E.Plan("cuda:0")
+    pk = E._std_pack(plan, w, 3, 1)
+    out = plan.buf(B, Cout, S, S)
+    gamma, beta = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.3
+    pre = E.Plan("cuda:0")
+    g = pre.gn_scale_shift(x, None, gamma, beta, B, S * S)
+    pre.run(); torch.cuda.synchronize()
+    plan._gn_src[id(g[0])] = (gamma, beta, (Cin // 32) * S * S, 1.0)
+    plan.conv(x, None, pk, bias, out, B=B, H=S, W=S, VH=S, VW=S, gn=g)
+    plan.pack_weights()
+    run_conv = plan.run
 Cc, L = (128, 65536) if what.endswith("16") else (256, 16384)
-qkv = torch.randn(B, 3 * Cc, L, device="cuda")
-o = torch.empty(B, Cc, L, device="cuda")
-lse = torch.empty(B, 8, L, device="cuda")
-if what.startswith("fwd"):
+if what != "conv3":
+    qkv = torch.randn(B, 3 * Cc, L, device="cuda")
+    o = torch.empty(B, Cc, L, device="cuda")
+    lse = torch.empty(B, 8, L, device="cuda")
+if what == "conv3":
+    def run():
+        for _ in range(50):
+            run_conv()
+elif what.startswith("fwd"):
     need = C.c_int64(0)
     lib.hdiff_mha_flash_fwd_workspace(B, Cc, 8, L, C.byref(need))
     ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device="cuda")
@@ -64,5 +87,7 @@ with clock:
     torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
 c = clock.summary()
+if what == "conv3":
+    ms /= 50
 print(f"{what} B={B} C={Cc} L={L}: {ms:.3f} ms per launch over {n} launches; sclk {c.get('sclk_mhz_mean')} MHz "
       f"(min {c.get('sclk_mhz_min')}, max {c.get('sclk_mhz_max')}), board {c.get('board_power_w_mean')} W", flush=True)
