@@ -21,10 +21,16 @@ inside a graph replay; the kernels, their arguments and their order are identica
 this size, both wall times are reported).
 
 Rank 0 prints ONE JSON line with the contract keys plus
-  roofline      dominant kernel (flash attention at L = 65536, d_head = 16) against the fp32-MFMA peak; ``secondary`` holds
-                the full-resolution 3x3 convolution (MFMA) and the GroupNorm statistics pass (HBM) the same way;
-                ``traffic`` comes from profiles/roofline_traffic.json and is reported only while the kernel sources still
-                hash to what that file was measured on (``traffic_stamp``)
+  roofline      dominant kernel (flash attention at L = 65536, d_head = 16): ``frac`` against the 16-bit dense MFMA peak / the
+                3.5 piece products it executes per fp32 product (fp32-MFMA peak in the f32 mode), ``frac_vs_16bit_peak`` against
+                the raw peak, ``issue_model_ms`` / ``frac_vs_issue_model`` (its own PMC instruction counts priced at issue cost at
+                the clock the run held), ``matrix_only_floor_ms_at_power_limit`` / ``frac_vs_matrix_only_floor`` (its MFMA count at
+                the rate a bare MFMA loop sustains on this board: the kernel is bound by the energy of its instruction stream at
+                the board's power limit, ``bound_note``); ``secondary`` holds the full-resolution 3x3 convolution (MFMA) and the
+                GroupNorm statistics pass (HBM); ``traffic`` and the instruction counts come from profiles/roofline_traffic.json
+                and are reported only while the kernel sources still hash to what that file was measured on (``traffic_stamp``)
+  device_clock / box_range   engine clock and board power of THIS run's device during the timed region; the range of the headline
+                over the boxes met (the power limit leaves different clocks on different boxes)
   cpu_baseline  the CPU oracle (oracle/cpu_path.py, kind "port"): one whole UNet forward at 128x128 timed on the host
                 cores (a bounded sample), scaled to the benchmark's step by the algorithmic FLOP ratio; ``same_config``
                 holds the one BASELINE config the CPU finishes in full (C1), timed on both sides
