@@ -175,39 +175,6 @@ class PackedConv:
 # ----------------------------------------------------------------------------------------------------------------------
 # Plan
 # ----------------------------------------------------------------------------------------------------------------------
-# Side lanes (round 6): launches that do not depend on their predecessors in plan order -- the 1x1 shortcut of a ResBlock beside the
-# GroupNorm / conv / GroupNorm chain of its main path, the four output-parity phases of a transposed convolution -- are tagged with a lane
-# number.  Plan order stays a valid SEQUENTIAL order (run() and every tool that walks `ops` issue it on one stream, as before); capture()
-# turns the lanes into parallel branches of the hipGraph (fork: the lane's stream waits for an event of the main stream; join: the main
-# stream waits for the lane's).  Only planes of at most FORK_MAX_PIXELS pixels fork: there a launch fills a fraction of the 256 CUs and the
-# step's time is the SUM of its kernels' own durations (BASELINE config C1: 157 launches, 3.7 ms); at full resolution every launch fills the
-# chip and a fork buys nothing.  Same kernels, same arguments, same arithmetic: replay equals plain launches bit for bit.
-FORK_MAX_PIXELS = 32768        # B * H * W of the launches that may run beside each other
-
-
-class _LaneFn:
-    """A C-ABI entry point tagged with the side lane its launch belongs to (called exactly like the entry point)."""
-    __slots__ = ("fn", "lane")
-
-    def __init__(self, fn: Callable, lane: int):
-        self.fn, self.lane = fn, lane
-
-    def __call__(self, *a):
-        return self.fn(*a)
-
-
-class _JoinFn:
-    """Pseudo-launch: the main lane waits for side lane `join` (a no-op when the plan is issued on one stream)."""
-    __slots__ = ("join",)
-    lane = 0
-
-    def __init__(self, lane: int):
-        self.join = lane
-
-    def __call__(self, *a):
-        return 0
-
-
 class Plan:
     """A static, replayable list of C-ABI launches over preallocated device buffers."""
 
@@ -226,10 +193,6 @@ class Plan:
         self._graph_stream: Optional[torch.cuda.Stream] = None
         self.flops = 0.0          # algorithmic FLOPs of the MFMA-bound launches (convolutions, attention) of one run
         self._vec_jobs: List[tuple] = []          # per-block embedding projections, emitted as ONE launch (flush_block_vecs)
-        self._lane = 0                            # lane of the launches being emitted (0 = main)
-        self._deferred_free: Dict[int, List[torch.Tensor]] = {}     # buffers freed inside a side lane: returned to the pool at its join
-        self._side_streams: Dict[int, torch.cuda.Stream] = {}
-        self._events: List[torch.cuda.Event] = []
 
     # -- memory -------------------------------------------------------------------------------------------------------
     def buf(self, *shape: int, dtype=torch.float32) -> torch.Tensor:
@@ -249,34 +212,7 @@ class Plan:
 
     def free(self, t: torch.Tensor) -> None:
         base = getattr(t, "_hdiff_base", None)
-        if base is None:
-            return
-        if self._lane:          # a side lane's scratch must not be handed to a launch that may run beside it: back to the pool at the join
-            self._deferred_free.setdefault(self._lane, []).append(base)
-        else:
-            self._pool.setdefault(base.numel() * 4, []).append(base)
-
-    # -- side lanes -----------------------------------------------------------------------------------------------------
-    def lane(self, k: int):
-        """Context manager: the launches emitted inside belong to side lane k (k >= 1) -- they may run beside the main lane's launches
-        emitted between here and ``join(k)``.  The caller guarantees that they read only buffers that stay live until the join and write
-        only buffers nobody touches before it, and emits a fork region's side-lane launches BEFORE its main-lane ones: a lane forks from
-        the main lane at its first launch, and scratch the main lane frees inside the region can then never be handed to a lane."""
-        plan = self
-
-        class _Ctx:
-            def __enter__(self_inner):
-                assert plan._lane == 0 and k >= 1
-                plan._lane = k
-
-            def __exit__(self_inner, *exc):
-                plan._lane = 0
-        return _Ctx()
-
-    def join(self, k: int) -> None:
-        assert self._lane == 0
-        self.ops.append(("_join", _JoinFn(k), ()))
-        for base in self._deferred_free.pop(k, []):
+        if base is not None:
             self._pool.setdefault(base.numel() * 4, []).append(base)
 
     def bytes_allocated(self) -> int:
@@ -284,8 +220,7 @@ class Plan:
 
     # -- launches -----------------------------------------------------------------------------------------------------
     def call(self, name: str, *args) -> None:
-        fn = getattr(self.lib, name)
-        self.ops.append((name, _LaneFn(fn, self._lane) if self._lane else fn, args))
+        self.ops.append((name, getattr(self.lib, name), args))
 
     def keep(self, obj) -> None:
         self._keep.append(obj)
@@ -318,46 +253,10 @@ class Plan:
             s = self._graph_stream.cuda_stream
             _capi.check(self.lib.hdiff_graph_begin(s), "graph_begin")
             try:
-                self._issue_forked(self._graph_stream)
+                self.run(s)
             finally:
                 rc = self.lib.hdiff_graph_end(s, C.byref(self.graph))
             _capi.check(rc, "graph_end")
-
-    def _issue_forked(self, main: "torch.cuda.Stream") -> None:
-        """The launch list with its side lanes on streams of their own (under capture: parallel branches of the graph)."""
-        assert not self._vec_jobs, "flush_block_vecs() was not called for this plan"
-        open_lanes: set = set()
-
-        def join(k: int) -> None:
-            ev = torch.cuda.Event()
-            ev.record(self._side_streams[k])
-            main.wait_event(ev)
-            self._events.append(ev)
-            open_lanes.discard(k)
-
-        for name, fn, args in self.ops:
-            j = getattr(fn, "join", None)
-            if j is not None:
-                if j in open_lanes:
-                    join(j)
-                continue
-            k = getattr(fn, "lane", 0)
-            if k == 0:
-                rc = fn(*args, main.cuda_stream)
-            else:
-                if k not in self._side_streams:
-                    self._side_streams[k] = torch.cuda.Stream(self.device)
-                if k not in open_lanes:          # fork: everything issued on the main lane so far happens before the lane's launches
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    self._side_streams[k].wait_event(ev)
-                    self._events.append(ev)
-                    open_lanes.add(k)
-                rc = fn(*args, self._side_streams[k].cuda_stream)
-            if rc != 0:
-                _capi.check(rc, name)
-        for k in sorted(open_lanes):
-            join(k)
 
     def replay(self, stream: Optional[int] = None) -> None:
         with torch.cuda.device(self.device):
@@ -601,15 +500,6 @@ def emit_attn_block(plan: Plan, P: Dict[str, torch.Tensor], p: str, x: torch.Ten
 def emit_resblock(plan: Plan, P: Dict[str, torch.Tensor], p: str, xa: torch.Tensor, xb: Optional[torch.Tensor],
                   temb: torch.Tensor, cemb: Optional[torch.Tensor], cout: int, B: int, H: int, W: int, attn: bool) -> torch.Tensor:
     """ResBlock.forward (ModelCondition.py:196-211) on the virtual concat [xa | xb]."""
-    has_shortcut = f"{p}.shortcut.weight" in P
-    fork = has_shortcut and B * H * W <= FORK_MAX_PIXELS       # small planes: the 1x1 shortcut runs BESIDE the main path's GroupNorm / conv / GroupNorm
-    res, res_owned = None, False
-    if fork:
-        pks = _std_pack(plan, P[f"{p}.shortcut.weight"], 1, 0)
-        res = plan.buf(B, cout, H, W)
-        with plan.lane(1):
-            plan.conv(xa, xb, pks, P[f"{p}.shortcut.bias"], res, B=B, H=H, W=W, VH=H, VW=W)
-        res_owned = True
     sc1 = plan.gn_scale_shift(xa, xb, P[f"{p}.block1.0.weight"], P[f"{p}.block1.0.bias"], B, H * W)
     vec = plan.block_vec(temb, cemb, P, p, B, cout)
     pk1 = _std_pack(plan, P[f"{p}.block1.2.weight"], 3, 1)
@@ -618,9 +508,7 @@ def emit_resblock(plan: Plan, P: Dict[str, torch.Tensor], p: str, xa: torch.Tens
     plan.free(sc1[0]); plan.free(sc1[1])
 
     sc2 = plan.gn_scale_shift(h1, None, P[f"{p}.block2.0.weight"], P[f"{p}.block2.0.bias"], B, H * W)
-    if fork:
-        plan.join(1)
-    elif has_shortcut:
+    if f"{p}.shortcut.weight" in P:
         pks = _std_pack(plan, P[f"{p}.shortcut.weight"], 1, 0)
         res = plan.buf(B, cout, H, W)
         plan.conv(xa, xb, pks, P[f"{p}.shortcut.bias"], res, B=B, H=H, W=W, VH=H, VW=W)
@@ -664,23 +552,13 @@ def emit_upsample(plan: Plan, P: Dict[str, torch.Tensor], p: str, x: torch.Tenso
     """UpSample.forward (ModelCondition.py:85-89): ConvTranspose2d(5,2,2,1) as 4 parity phases, then Conv3x3."""
     wt = P[f"{p}.t.weight"]                      # [Cin][Cout][5][5]
     u = plan.buf(B, Cc, 2 * H, 2 * W)
-    fork = B * H * W <= FORK_MAX_PIXELS          # small planes: the four phases (disjoint output pixels, one input) run beside each other
-    # (forked: phases 3, 2, 1 on side lanes FIRST, phase 0 on the main lane behind them -- a lane forks from the main lane at its first
-    #  launch, so what the main lane issued before that point would run ahead of it, not beside it)
-    for k in ((3, 2, 1, 0) if fork else (0, 1, 2, 3)):
-        py, px = k >> 1, k & 1
-        taps = tconv_phase_taps(py, px)
-        pk = _new_pack(plan, Cc, Cc, taps)
-        pk.add_source(wt, 1, taps.ky, taps.kx, 0)
-        pk.enable_x3_taps(wt, 1)             # every phase's taps lie in the 3x3 neighbourhood: the split-bf16 kernel serves them
-        if fork and k:
-            with plan.lane(k):
-                plan.conv(x, None, pk, P[f"{p}.t.bias"], u, B=B, H=H, W=W, VH=H, VW=W, out_map=(2, py, 2, px))
-        else:
+    for py in (0, 1):
+        for px in (0, 1):
+            taps = tconv_phase_taps(py, px)
+            pk = _new_pack(plan, Cc, Cc, taps)
+            pk.add_source(wt, 1, taps.ky, taps.kx, 0)
+            pk.enable_x3_taps(wt, 1)             # every phase's taps lie in the 3x3 neighbourhood: the split-bf16 kernel serves them
             plan.conv(x, None, pk, P[f"{p}.t.bias"], u, B=B, H=H, W=W, VH=H, VW=W, out_map=(2, py, 2, px))
-    if fork:
-        for k in (1, 2, 3):
-            plan.join(k)
     pkc = _std_pack(plan, P[f"{p}.c.weight"], 3, 1)
     y = plan.buf(B, Cc, 2 * H, 2 * W)
     plan.conv(u, None, pkc, P[f"{p}.c.bias"], y, B=B, H=2 * H, W=2 * W, VH=2 * H, VW=2 * W)

@@ -27,8 +27,6 @@ s = torch.cuda.current_stream().cuda_stream
 rows = collections.OrderedDict()
 total = 0.0
 for name, fn, args in plan.ops:
-    if name == '_join':          # round 6: the join marker of a side lane (engine.Plan.join): not a launch
-        continue
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fn(*args, s)
     e0.record()
@@ -49,8 +47,7 @@ for name, fn, args in plan.ops:
     r[0] += 1
     r[1] += ms
     r[2] += flops
-nl = sum(1 for n_, _, _ in plan.ops if n_ != '_join')
-print(f"plan {size}x{size} batch {B}: {nl} launches, sum of stand-alone times {total:.1f} ms")
+print(f"plan {size}x{size} batch {B}: {len(plan.ops)} launches, sum of stand-alone times {total:.1f} ms")
 for key, (n, ms, fl) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
     tf = f"{fl / ms / 1e9:7.1f} TFLOP/s" if fl else ""
     print(f"{key:60s} x{n:3d} {ms:9.3f} ms {100 * ms / total:5.1f}%  {tf}")
