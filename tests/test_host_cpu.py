@@ -203,6 +203,26 @@ def test_psnr_ssim_definitions():
     assert 0 < p < 20 and -1 <= s <= 1
 
 
+def test_native_optimizer_is_a_torch_optimizer_and_refuses_cpu_parameters():
+    """hdiff_amd.optim.AdamW (the clip + AdamW tail of a training step, csrc/optimizer.hip) without a GPU: constructs like torch's, takes the
+    reference's schedulers, validates its hyper-parameters -- and raises on CPU parameters (no CPU path, like every operator of the package)."""
+    from hdiff_amd import optim as HO
+    from hdiff_amd.Scheduler import GradualWarmupScheduler
+    p = torch.nn.Parameter(torch.randn(8))
+    opt = HO.AdamW([p], lr=1e-4, weight_decay=1e-4)
+    assert isinstance(opt, torch.optim.Optimizer) and opt.param_groups[0]["lr"] == 1e-4 and opt.param_groups[0]["weight_decay"] == 1e-4
+    GradualWarmupScheduler(optimizer=opt, multiplier=2.5, warm_epoch=2,
+                           after_scheduler=torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=opt, T_max=20, eta_min=0, last_epoch=-1))
+    assert opt.step() is None                       # no gradients yet: nothing to do, like torch
+    p.grad = torch.randn(8)
+    with pytest.raises(RuntimeError, match="GPU"):
+        opt.step(max_grad_norm=1.0)
+    with pytest.raises(ValueError):
+        HO.AdamW([p], lr=-1.0)
+    with pytest.raises(ValueError):
+        HO.AdamW([p], betas=(1.0, 0.999))
+
+
 def test_ssim_psnr_hand_computed_single_window():
     """The hand-worked SSIM / PSNR values of tests/test_gpu_metrics.py (one 7x7 window, integers only) on the CPU suite too."""
     import test_gpu_metrics as G
