@@ -825,6 +825,9 @@ __global__ void mha_dq_reduce_h2_kernel(const float* __restrict__ part, float* _
 #define H2P_OPT 3             // switches of the pipelined kernel (A/B builds with -DH2P_OPT=<bits>): 1 static priority for waves 4-7 (the second-dispatched
 #endif                        // half loses every issue arbitration to its SIMD partner otherwise: -1.3 %), 2 no trailing s_nop in the dS split statements
                               // (the slot program puts an MFMA behind each: the partial-write hazard is covered; 0.0 %)
+#ifndef H2P_T4
+#define H2P_T4 1              // dev: 0 = the fourth terms of the two d-contracted products (q1 k1 in S', o1 v1 in dP': 2^-22 of their product) multiplied by
+#endif                        // ZEROS -- the stationary operands' high-half lanes cleared once per key block: same MFMAs, idle multipliers (energy A/B)
 #ifndef H2P_KTREG
 #define H2P_KTREG 1           // 1 = the dq stage's k^T operands in 16 registers for the whole sweep (the steady loop has no spill with them; -1.3 %),
 #endif                        // 0 = four LDS reads per tile out of a copy in MFMA operand order (A/B)
@@ -960,6 +963,7 @@ __global__ __launch_bounds__(MTHREADS) void mha_bwd_h2p_kernel(const BwdH2Args a
         const size_t row = (size_t)(key0 + kt * 16 + i16) * D + doff;
         kB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_K + 2 * j + (hi ? 1 : 0)) * piece_n + row);      // (k0 | k0 2^-8), (k1 2^8 | k1)
         vB[kt][j] = *reinterpret_cast<const u32x4*>(wsh + (size_t)(S_V + j) * piece_n + row);                          // (o0 | o1)(v_j | v_j)
+        if (!H2P_T4 && j == 1 && hi) { kB[kt][j] = u32x4{0u, 0u, 0u, 0u}; vB[kt][j] = u32x4{0u, 0u, 0u, 0u}; }
       }
     // k^T of this wave's 32 keys (rows d = i16, keys along the contraction) in MFMA operand order into LDS: the dq stage reads the two waves
     // of its key quarter from there every tile (lane-contiguous 16-byte reads) instead of holding 16 registers for the whole sweep
