@@ -63,7 +63,7 @@ MFMA16_NS_AT_POWER_LIMIT = 8.1    # tools/mfma_k16_probe.hip (profiles/r06_atten
 N_SIMD = 1024                     # 256 CUs x 4
 # The headline is ONE sample of a box-to-box range (same build, different boxes of the pool: the kernel sits on the board's power limit and boxes
 # hold different clocks there).  Measured ranges of the round, updated with the round's records:
-BOX_RANGE = {"denoising_steps_per_s": [2.76, 3.00], "sclk_mhz_mean": [2159, 2315], "board_power_w_mean": [1301, 1332],
+BOX_RANGE = {"denoising_steps_per_s": [2.76, 3.00], "sclk_mhz_mean": [2159, 2315],      # this round's two driver-shaped runs: 2.866 @ 2199 MHz, 2.919 @ 2254 MHz "board_power_w_mean": [1301, 1332],
              "what": "256x256, batch 8 headline on the boxes met in rounds 5-6 (lowest = a heat-soaked device right after the GPU suite)",
              "source": "profiles/r05_bench_full_line*.json, profiles/r06_bench_full_line*.json"}
 SCLK_MAX_MHZ = 2400.0             # MI355X_MICROARCH.md: engine clock ceiling
